@@ -1,0 +1,162 @@
+/*
+ * leon.h -- C ABI of the MI355X-native macroblock-reconstruction path
+ *           (libleon_hip.so; gfx950 only).
+ *
+ * This is the drop-in boundary for the ONE hot path of the reference decoder:
+ * everything the reference does between "the slice loop has filled the
+ * per-picture arrays" and "decoded planes are on the GPU / an RGBA frame is on
+ * the canvas".  Each entry point names the reference interface it replaces
+ * (paths under /root/reference).  Plain pointers and sizes only; no torch, no
+ * HIP types.  There is NO CPU fallback: every call fails with LEON_ERR_NO_DEVICE
+ * when no gfx950 device is usable.
+ *
+ * Data handed over per picture -- exactly the arrays
+ * jsv.prototype.IDCT_GL uploads with texImage2D (decoders/jsv.js:1204-1298):
+ *   coef_y/cb/cr  int16 LE dense planes of RAW quantised levels (intra DC in the
+ *                 0..255 predictor domain), natural order, at the pixel position
+ *                 of their block; row stride = plane width   (jsv.js:1237-1243)
+ *   qscale        u8 [mbH][mbW] quantiser_scale per macroblock (jsv.js:1204-1206)
+ *   intra         u8 [mbH][mbW] non-zero = intra macroblock    (jsv.js:1215-1217)
+ *   repadd        u8 [mbH][mbW] >=128 = replace (no prediction) (jsv.js:1282-1284)
+ *   mv_fwd        int16 [mbH][mbW][2] (H,V) luma half-pel units (jsv.js:1296-1298)
+ *   mv_bwd,mb_dir B pictures only (beyond the reference, ISO 11172-2 2.4.4.3):
+ *                 backward vectors, and per-MB direction bits 1=fwd 2=bwd
+ * Arithmetic domain: |level| <= 32767, qscale 0..31, matrix entries 0..255.
+ */
+#ifndef LEON_H
+#define LEON_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LEON_ABI_VERSION 1
+
+enum {
+    LEON_OK = 0,
+    LEON_ERR_INVALID = -1,      /* bad argument (shape, slot, type) */
+    LEON_ERR_NO_DEVICE = -2,    /* no usable gfx950 device / HIP failure at create */
+    LEON_ERR_HIP = -3,          /* a HIP call failed; see leon_last_error() */
+    LEON_ERR_NO_FREE_SLOT = -4, /* = throw "no free render buffers" (jsv.js:1175) */
+    LEON_ERR_NOMEM = -5
+};
+
+/* pictureCodingType values of the reference (decoders/jsv.js PICTURE_TYPE_*) */
+enum { LEON_PIC_I = 1, LEON_PIC_P = 2, LEON_PIC_B = 3 };
+
+/* where the pointers of a leon_picture / rgba destination live */
+enum { LEON_MEM_HOST = 0, LEON_MEM_DEVICE = 1 };
+
+/* colour conversion flavour of leon_convert_rgba */
+enum {
+    LEON_RGB_CPU_TWIN = 0, /* fp64, = jsv.prototype.YCbCrToRGBA player/easybits.player.js:2674-2785 (parity target) */
+    LEON_RGB_GL = 1        /* fp32 matrix, = SHADER_FRAGMENT_YCBCRTORGBA player/parts/end.js:77-156 */
+};
+
+typedef struct leon_decoder leon_decoder;
+typedef struct leon_batch leon_batch;
+
+typedef struct leon_config {
+    int32_t coded_width;   /* mbWidth<<4  (jsv.js:364) */
+    int32_t coded_height;  /* mbHeight<<4 (jsv.js:365) */
+    int32_t frame_width;   /* display crop (jsv.js:360-361, player.js:820-821) */
+    int32_t frame_height;
+    int32_t n_slots;       /* output ring; the reference uses 13 (jsv.js:24, :58-73) */
+    int32_t device_id;     /* HIP device ordinal */
+    void*   stream;        /* hipStream_t to run on, or NULL: the decoder owns one */
+} leon_config;
+
+typedef struct leon_picture {
+    int32_t type;          /* LEON_PIC_I / _P / _B */
+    int32_t out_slot;      /* slot to write (from leon_acquire_slot or caller-managed) */
+    int32_t ref_fwd_slot;  /* P, B: forward reference = prev_pic_framebuffer (jsv.js:665, :1320) */
+    int32_t ref_bwd_slot;  /* B only */
+    const int16_t* coef_y;
+    const int16_t* coef_cb;
+    const int16_t* coef_cr;
+    const uint8_t* qscale;
+    const uint8_t* intra;
+    const uint8_t* repadd; /* P, B */
+    const int16_t* mv_fwd; /* P, B */
+    const int16_t* mv_bwd; /* B */
+    const uint8_t* mb_dir; /* B */
+} leon_picture;
+
+typedef struct leon_kernel_stats {
+    uint64_t launches;        /* timed launches since leon_timing_reset */
+    double   total_ms;        /* sum of their HIP-event durations */
+    double   algorithmic_bytes; /* sum over launches of SURVEY.md 8d bytes */
+    uint64_t macroblocks;     /* sum over launches */
+} leon_kernel_stats;
+
+int leon_abi_version(void);
+
+/* thread-local text of the last error returned on this thread */
+const char* leon_last_error(void);
+
+/* = new jsv_dec + decoder._initGL(gl) + initGLBuffers (player/easybits.player.js:584-585,
+ *   decoders/jsv.js:88-208, :51-87): allocates the slot ring and uploads the default
+ *   quant matrices + premultiplier (jsv.js:139-150). */
+int leon_create(const leon_config* cfg, leon_decoder** out);
+void leon_destroy(leon_decoder* d);
+
+/* = the QUANT_MATRIX re-uploads on a sequence header (decoders/jsv.js:540-558).
+ *   64 bytes each, natural (de-zig-zagged) order; NULL keeps the current one. */
+int leon_set_quant_matrices(leon_decoder* d, const uint8_t* intra64, const uint8_t* non_intra64);
+
+/* = jsv.prototype.setRenderBuffer (decoders/jsv.js:1165-1176): first free slot, marked in use */
+int leon_acquire_slot(leon_decoder* d, int32_t* slot);
+/* = texture.inuse = false in renderFrameGL (player/easybits.player.js:2820) */
+int leon_release_slot(leon_decoder* d, int32_t slot);
+/* = jsv.prototype.GLfreeDecodedBuffers (decoders/jsv.js:1160-1164), used by seek (:1623) */
+int leon_free_decoded_slots(leon_decoder* d);
+
+/* = jsv.prototype.IDCT_GL (decoders/jsv.js:1177-1336) for one picture whose arrays
+ *   are in host memory: staged to the device and reconstructed asynchronously on the
+ *   decoder's stream.  The arrays may be reused as soon as the call returns. */
+int leon_submit_picture(leon_decoder* d, const leon_picture* pic);
+
+/* Batched IDCT_GL: n mutually independent pictures in ONE kernel launch.
+ * mem = LEON_MEM_DEVICE: every pointer in pics[] is a device pointer (resident
+ * boundary tensors; the arrays must stay valid until the work completed).
+ * mem = LEON_MEM_HOST: staged like leon_submit_picture. */
+int leon_submit_batch(leon_decoder* d, const leon_picture* pics, int32_t n, int32_t mem);
+
+/* A prepared batch keeps its descriptors on the device so that re-running it costs
+ * one kernel launch and no copies (device-resident pictures only). */
+int leon_batch_create(leon_decoder* d, const leon_picture* pics, int32_t n, leon_batch** out);
+int leon_batch_run(leon_decoder* d, const leon_batch* b);
+void leon_batch_destroy(leon_decoder* d, leon_batch* b);
+
+/* = renderFrameGL(_frame) (player/easybits.player.js:2787-2858) / YCbCrToRGBA (:2674-2785):
+ *   slot -> RGBA8 frame_width x frame_height, tightly packed.  dst_mem says where
+ *   rgba lives.  Does NOT release the slot (call leon_release_slot). */
+int leon_convert_rgba(leon_decoder* d, int32_t slot, void* rgba, int32_t dst_mem, int32_t flavour);
+/* n slots -> n consecutive RGBA frames in device memory, one launch */
+int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, void* rgba_device, int32_t flavour);
+
+/* test / read-back helpers (the reference never reads planes back; dumpPixels2
+ * decoders/jsv.js:1141-1159 is its only analogue) */
+int leon_read_planes(leon_decoder* d, int32_t slot, uint8_t* y, uint8_t* cb, uint8_t* cr);
+int leon_write_planes(leon_decoder* d, int32_t slot, const uint8_t* y, const uint8_t* cb, const uint8_t* cr);
+/* device address of a slot's [Y|Cb|Cr] planes (for zero-copy consumers) */
+int leon_slot_device_ptr(leon_decoder* d, int32_t slot, void** ptr, size_t* bytes);
+
+/* wait for everything submitted so far */
+int leon_sync(leon_decoder* d);
+
+/* HIP-event timing of the kernels launched by this decoder (bench.py roofline).
+ * kind: 0 = reconstruction kernel (dequant+IDCT+MC), 1 = colour conversion. */
+int leon_timing_enable(leon_decoder* d, int32_t on);
+int leon_timing_reset(leon_decoder* d);
+int leon_timing_get(leon_decoder* d, int32_t kind, leon_kernel_stats* out);
+
+/* measured device copy bandwidth (GB/s) over `bytes` with a streaming float4
+ * copy kernel: the "measured HBM roofline" of BASELINE.md section 2 */
+int leon_measure_copy_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, double* gbps);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,680 @@
+// leon_hip.cpp -- the C ABI of include/leon.h over HIP (gfx950).
+// Compiled with hipcc -x hip; see mpeg1video-decoder-webgl_amd/csrc/Makefile.
+// There is no CPU path in this library: without a device every call fails.
+#include "leon_kernels.h"
+#include "../../include/leon.h"
+
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+using namespace leon;
+
+namespace {
+
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...)
+{
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_err = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                      \
+    do {                                                                                   \
+        hipError_t e_ = (expr);                                                            \
+        if (e_ != hipSuccess) return fail(LEON_ERR_HIP, "%s: %s", #expr, hipGetErrorString(e_)); \
+    } while (0)
+
+// decoders/jsv.js:1777-1806 default tables (same data as the oracle's, stated here
+// because the product never links the oracle)
+const uint8_t kDefaultIntra[64] = {
+     8, 16, 19, 22, 26, 27, 29, 34, 16, 16, 22, 24, 27, 29, 34, 37,
+    19, 22, 26, 27, 29, 34, 34, 38, 22, 22, 26, 27, 29, 34, 37, 40,
+    22, 26, 27, 29, 32, 35, 40, 48, 26, 27, 29, 32, 35, 40, 48, 58,
+    26, 27, 29, 34, 38, 46, 56, 69, 27, 29, 35, 38, 46, 56, 69, 83};
+const uint8_t kPremultiplier[64] = {
+    32, 44, 42, 38, 32, 25, 17,  9, 44, 62, 58, 52, 44, 35, 24, 12,
+    42, 58, 55, 49, 42, 33, 23, 12, 38, 52, 49, 44, 38, 30, 20, 10,
+    32, 44, 42, 38, 32, 25, 17,  9, 25, 35, 33, 30, 25, 20, 14,  7,
+    17, 24, 23, 20, 17, 14,  9,  5,  9, 12, 12, 10,  9,  7,  5,  2};
+
+struct TimedLaunch {
+    hipEvent_t a, b;
+    int kind;
+    double bytes;
+    uint64_t mbs;
+};
+
+// SURVEY.md 8d / BASELINE.md section 2: algorithmic bytes per macroblock
+double algo_bytes_per_mb(int type) { return type == LEON_PIC_I ? 1154.0 : type == LEON_PIC_P ? 1542.0 : 1930.0; }
+const double kRgbaBytesPerMb = 1408.0;
+
+struct Staging {                 // device copy of one host-submitted picture
+    char* base = nullptr;
+    hipEvent_t done = nullptr;
+    bool busy = false;
+};
+
+}  // namespace
+
+struct leon_batch {
+    PicDesc* d_descs = nullptr;
+    int n = 0;
+    double bytes = 0;
+    uint64_t mbs = 0;
+};
+
+struct leon_decoder {
+    leon_config cfg{};
+    int dev = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    Geom geom{};
+    size_t plane_bytes = 0;      // cw*ch*3/2
+    size_t slot_stride = 0;      // padded
+    uint8_t* d_slots = nullptr;
+    std::vector<uint8_t> inuse;
+    Tables h_tables{};
+    Tables* d_tables = nullptr;
+    uint8_t qm[128];
+    // host-submit staging ring
+    static constexpr int kStages = 4;
+    Staging stages[kStages];
+    size_t stage_bytes = 0;
+    int next_stage = 0;
+    PicDesc* d_desc_ring = nullptr;   // kDescRing descriptors for ad-hoc submits
+    PicDesc* h_desc_pinned = nullptr;
+    static constexpr int kDescRing = 4096;
+    int desc_head = 0;
+    hipEvent_t desc_wrap_ev = nullptr;
+    // rgba
+    int32_t* d_slot_ids = nullptr;
+    int32_t* h_slot_ids = nullptr;
+    static constexpr int kSlotIdRing = 8192;
+    int slot_id_head = 0;
+    uint8_t* d_rgba_tmp = nullptr;
+    // timing
+    bool timing = false;
+    std::vector<TimedLaunch> timed;
+    std::vector<hipEvent_t> ev_pool;
+};
+
+namespace {
+
+hipEvent_t get_event(leon_decoder* d)
+{
+    if (!d->ev_pool.empty()) {
+        hipEvent_t e = d->ev_pool.back();
+        d->ev_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+
+void upload_tables(leon_decoder* d)
+{
+    for (int c = 0; c < 8; c++)
+        for (int i = 0; i < 8; i++) {
+            d->h_tables.qmT[0][c][i] = d->qm[i * 8 + c];
+            d->h_tables.qmT[1][c][i] = d->qm[64 + i * 8 + c];
+            d->h_tables.pmT[c][i] = kPremultiplier[i * 8 + c];
+        }
+}
+
+int check_pic(const leon_decoder* d, const leon_picture& p)
+{
+    if (p.type < LEON_PIC_I || p.type > LEON_PIC_B) return fail(LEON_ERR_INVALID, "picture type %d", p.type);
+    if (p.out_slot < 0 || p.out_slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "out_slot %d", p.out_slot);
+    if (!p.coef_y || !p.coef_cb || !p.coef_cr || !p.qscale || !p.intra) return fail(LEON_ERR_INVALID, "null boundary tensor");
+    if (p.type != LEON_PIC_I) {
+        if (p.ref_fwd_slot < 0 || p.ref_fwd_slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "ref_fwd_slot %d", p.ref_fwd_slot);
+        if (!p.repadd || !p.mv_fwd) return fail(LEON_ERR_INVALID, "P/B picture without repadd/mv_fwd");
+        if (p.ref_fwd_slot == p.out_slot) return fail(LEON_ERR_INVALID, "out_slot equals ref_fwd_slot");
+    }
+    if (p.type == LEON_PIC_B) {
+        if (p.ref_bwd_slot < 0 || p.ref_bwd_slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "ref_bwd_slot %d", p.ref_bwd_slot);
+        if (!p.mv_bwd || !p.mb_dir) return fail(LEON_ERR_INVALID, "B picture without mv_bwd/mb_dir");
+        if (p.ref_bwd_slot == p.out_slot) return fail(LEON_ERR_INVALID, "out_slot equals ref_bwd_slot");
+    }
+    return LEON_OK;
+}
+
+void fill_desc(const leon_decoder* d, const leon_picture& p, PicDesc& o)
+{
+    o.coef[0] = p.coef_y;
+    o.coef[1] = p.coef_cb;
+    o.coef[2] = p.coef_cr;
+    o.qscale = p.qscale;
+    o.intra = p.intra;
+    o.repadd = p.repadd;
+    o.mb_dir = p.mb_dir;
+    o.mv_fwd = p.mv_fwd;
+    o.mv_bwd = p.mv_bwd;
+    o.out = d->d_slots + (size_t)p.out_slot * d->slot_stride;
+    o.ref_fwd = p.type != LEON_PIC_I ? d->d_slots + (size_t)p.ref_fwd_slot * d->slot_stride : nullptr;
+    o.ref_bwd = p.type == LEON_PIC_B ? d->d_slots + (size_t)p.ref_bwd_slot * d->slot_stride : nullptr;
+    o.type = p.type;
+    o.pad_ = 0;
+}
+
+int launch_recon(leon_decoder* d, const PicDesc* d_descs, int n, double bytes, uint64_t mbs)
+{
+    Geom G = d->geom;
+    G.n_pics = n;
+    long long waves = (long long)n * G.tasks_per_pic;
+    G.n_wg = (int)((waves + kWavesPerWG - 1) / kWavesPerWG);
+    TimedLaunch tl{};
+    if (d->timing) {
+        tl.a = get_event(d);
+        tl.b = get_event(d);
+        tl.kind = 0;
+        tl.bytes = bytes;
+        tl.mbs = mbs;
+        HIP_TRY(hipEventRecord(tl.a, d->stream));
+    }
+    hipLaunchKernelGGL(k_recon, dim3(G.n_wg), dim3(64 * kWavesPerWG), kWavesPerWG * kLdsPerWave, d->stream,
+                       d_descs, G, d->d_tables);
+    HIP_TRY(hipGetLastError());
+    if (d->timing) {
+        HIP_TRY(hipEventRecord(tl.b, d->stream));
+        d->timed.push_back(tl);
+    }
+    return LEON_OK;
+}
+
+void batch_cost(const leon_decoder* d, const leon_picture* pics, int n, double& bytes, uint64_t& mbs)
+{
+    uint64_t per = (uint64_t)d->geom.mbw * d->geom.mbh;
+    bytes = 0;
+    for (int i = 0; i < n; i++) bytes += algo_bytes_per_mb(pics[i].type) * (double)per;
+    mbs = per * (uint64_t)n;
+}
+
+// reserve n consecutive descriptors in the ring (wrap = wait for the previous lap)
+int reserve_descs(leon_decoder* d, int n, int& at)
+{
+    if (n > leon_decoder::kDescRing) return fail(LEON_ERR_INVALID, "batch of %d pictures exceeds %d; use leon_batch_create", n, leon_decoder::kDescRing);
+    if (d->desc_head + n > leon_decoder::kDescRing) {
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        d->desc_head = 0;
+    }
+    at = d->desc_head;
+    d->desc_head += n;
+    return LEON_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+int leon_abi_version(void) { return LEON_ABI_VERSION; }
+
+const char* leon_last_error(void) { return g_err.c_str(); }
+
+int leon_create(const leon_config* cfg, leon_decoder** out)
+{
+    if (!cfg || !out) return fail(LEON_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (cfg->coded_width <= 0 || cfg->coded_height <= 0 || (cfg->coded_width & 15) || (cfg->coded_height & 15))
+        return fail(LEON_ERR_INVALID, "coded size %dx%d must be positive multiples of 16", cfg->coded_width, cfg->coded_height);
+    if (cfg->frame_width <= 0 || cfg->frame_height <= 0 || cfg->frame_width > cfg->coded_width || cfg->frame_height > cfg->coded_height)
+        return fail(LEON_ERR_INVALID, "frame size %dx%d", cfg->frame_width, cfg->frame_height);
+    if (cfg->n_slots < 1) return fail(LEON_ERR_INVALID, "n_slots %d", cfg->n_slots);
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
+        return fail(LEON_ERR_NO_DEVICE, "no HIP device: this library has no CPU fallback");
+    if (cfg->device_id < 0 || cfg->device_id >= ndev) return fail(LEON_ERR_NO_DEVICE, "device %d of %d", cfg->device_id, ndev);
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, cfg->device_id) != hipSuccess) return fail(LEON_ERR_NO_DEVICE, "hipGetDeviceProperties failed");
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(LEON_ERR_NO_DEVICE, "device %d is %s; this library is built for gfx950 only", cfg->device_id, prop.gcnArchName);
+    HIP_TRY(hipSetDevice(cfg->device_id));
+
+    leon_decoder* d = new (std::nothrow) leon_decoder();
+    if (!d) return fail(LEON_ERR_NOMEM, "out of host memory");
+    d->cfg = *cfg;
+    d->dev = cfg->device_id;
+    if (cfg->stream) {
+        d->stream = (hipStream_t)cfg->stream;
+    } else {
+        if (hipStreamCreateWithFlags(&d->stream, hipStreamNonBlocking) != hipSuccess) {
+            delete d;
+            return fail(LEON_ERR_HIP, "hipStreamCreate failed");
+        }
+        d->own_stream = true;
+    }
+    Geom& G = d->geom;
+    G.cw = cfg->coded_width;
+    G.ch = cfg->coded_height;
+    G.mbw = G.cw >> 4;
+    G.mbh = G.ch >> 4;
+    G.gY = ((G.cw >> 3) + 7) >> 3;
+    G.gC = ((G.cw >> 4) + 7) >> 3;
+    G.tasksY = G.gY * (G.ch >> 3);
+    G.tasksC = G.gC * (G.ch >> 4);
+    G.tasks_per_pic = G.tasksY + 2 * G.tasksC;
+    d->plane_bytes = (size_t)G.cw * G.ch * 3 / 2;
+    d->slot_stride = (d->plane_bytes + 255) / 256 * 256 + 256;   // tail pad: the 12-byte MC window may over-read 3 bytes
+    d->inuse.assign(cfg->n_slots, 0);
+    auto bail = [&](const char* what) {
+        std::string msg = std::string(what) + ": " + hipGetErrorString(hipGetLastError());
+        leon_destroy(d);
+        return fail(LEON_ERR_NOMEM, "%s", msg.c_str());
+    };
+    if (hipMalloc(&d->d_slots, d->slot_stride * (size_t)cfg->n_slots + 256) != hipSuccess) return bail("slot ring");
+    if (hipMemsetAsync(d->d_slots, 0, d->slot_stride * (size_t)cfg->n_slots + 256, d->stream) != hipSuccess) return bail("slot memset");
+    if (hipMalloc(&d->d_tables, sizeof(Tables)) != hipSuccess) return bail("tables");
+    memcpy(d->qm, kDefaultIntra, 64);
+    memset(d->qm + 64, 16, 64);
+    upload_tables(d);
+    if (hipMemcpyAsync(d->d_tables, &d->h_tables, sizeof(Tables), hipMemcpyHostToDevice, d->stream) != hipSuccess) return bail("tables upload");
+    if (hipMalloc(&d->d_desc_ring, sizeof(PicDesc) * leon_decoder::kDescRing) != hipSuccess) return bail("descriptor ring");
+    if (hipHostMalloc((void**)&d->h_desc_pinned, sizeof(PicDesc) * leon_decoder::kDescRing) != hipSuccess) return bail("pinned descriptors");
+    if (hipMalloc(&d->d_slot_ids, sizeof(int32_t) * leon_decoder::kSlotIdRing) != hipSuccess) return bail("slot id ring");
+    if (hipHostMalloc((void**)&d->h_slot_ids, sizeof(int32_t) * leon_decoder::kSlotIdRing) != hipSuccess) return bail("pinned slot ids");
+    // staging for host-memory pictures: coef planes (2 bytes/sample) + 5 byte maps + 2 vector maps
+    size_t mbs = (size_t)G.mbw * G.mbh;
+    d->stage_bytes = d->plane_bytes * 2 + 4 * ((mbs + 255) / 256 * 256) + 2 * ((mbs * 4 + 255) / 256 * 256) + 1024;
+    if (hipStreamSynchronize(d->stream) != hipSuccess) return bail("create sync");
+    *out = d;
+    return LEON_OK;
+}
+
+void leon_destroy(leon_decoder* d)
+{
+    if (!d) return;
+    hipSetDevice(d->dev);
+    if (d->stream) hipStreamSynchronize(d->stream);
+    for (auto& t : d->timed) {
+        hipEventDestroy(t.a);
+        hipEventDestroy(t.b);
+    }
+    for (auto e : d->ev_pool) hipEventDestroy(e);
+    for (auto& s : d->stages) {
+        if (s.base) hipFree(s.base);
+        if (s.done) hipEventDestroy(s.done);
+    }
+    if (d->d_slots) hipFree(d->d_slots);
+    if (d->d_tables) hipFree(d->d_tables);
+    if (d->d_desc_ring) hipFree(d->d_desc_ring);
+    if (d->h_desc_pinned) hipHostFree(d->h_desc_pinned);
+    if (d->d_slot_ids) hipFree(d->d_slot_ids);
+    if (d->h_slot_ids) hipHostFree(d->h_slot_ids);
+    if (d->d_rgba_tmp) hipFree(d->d_rgba_tmp);
+    if (d->own_stream && d->stream) hipStreamDestroy(d->stream);
+    delete d;
+}
+
+int leon_set_quant_matrices(leon_decoder* d, const uint8_t* intra64, const uint8_t* non_intra64)
+{
+    if (!d) return fail(LEON_ERR_INVALID, "null decoder");
+    HIP_TRY(hipSetDevice(d->dev));
+    if (intra64) memcpy(d->qm, intra64, 64);
+    if (non_intra64) memcpy(d->qm + 64, non_intra64, 64);
+    // in-flight kernels read d_tables: order the update behind them, and keep the
+    // host copy stable until the copy has been consumed
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    upload_tables(d);
+    HIP_TRY(hipMemcpyAsync(d->d_tables, &d->h_tables, sizeof(Tables), hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LEON_OK;
+}
+
+int leon_acquire_slot(leon_decoder* d, int32_t* slot)
+{
+    if (!d || !slot) return fail(LEON_ERR_INVALID, "null argument");
+    for (int j = 0; j < d->cfg.n_slots; j++)
+        if (!d->inuse[j]) {
+            d->inuse[j] = 1;
+            *slot = j;
+            return LEON_OK;
+        }
+    return fail(LEON_ERR_NO_FREE_SLOT, "no free render buffers");
+}
+
+int leon_release_slot(leon_decoder* d, int32_t slot)
+{
+    if (!d || slot < 0 || slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "slot %d", slot);
+    d->inuse[slot] = 0;
+    return LEON_OK;
+}
+
+int leon_free_decoded_slots(leon_decoder* d)
+{
+    if (!d) return fail(LEON_ERR_INVALID, "null decoder");
+    std::fill(d->inuse.begin(), d->inuse.end(), 0);
+    return LEON_OK;
+}
+
+int leon_submit_batch(leon_decoder* d, const leon_picture* pics, int32_t n, int32_t mem)
+{
+    if (!d || !pics || n <= 0) return fail(LEON_ERR_INVALID, "bad batch");
+    HIP_TRY(hipSetDevice(d->dev));
+    for (int i = 0; i < n; i++) {
+        int rc = check_pic(d, pics[i]);
+        if (rc != LEON_OK) return rc;
+    }
+    if (n <= 64)   // pictures of one launch must be mutually independent (O(n^2): small batches only)
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < i; j++)
+                if (pics[j].out_slot == pics[i].out_slot ||
+                    (pics[i].type != LEON_PIC_I && pics[i].ref_fwd_slot == pics[j].out_slot) ||
+                    (pics[i].type == LEON_PIC_B && pics[i].ref_bwd_slot == pics[j].out_slot) ||
+                    (pics[j].type != LEON_PIC_I && pics[j].ref_fwd_slot == pics[i].out_slot) ||
+                    (pics[j].type == LEON_PIC_B && pics[j].ref_bwd_slot == pics[i].out_slot))
+                    return fail(LEON_ERR_INVALID, "pictures %d and %d of one batch depend on each other", j, i);
+    if (mem == LEON_MEM_HOST) {
+        if (n != 1) {
+            for (int i = 0; i < n; i++) {
+                int rc = leon_submit_picture(d, &pics[i]);
+                if (rc != LEON_OK) return rc;
+            }
+            return LEON_OK;
+        }
+        return leon_submit_picture(d, pics);
+    }
+    int at = 0;
+    int rc = reserve_descs(d, n, at);
+    if (rc != LEON_OK) return rc;
+    for (int i = 0; i < n; i++) fill_desc(d, pics[i], d->h_desc_pinned[at + i]);
+    HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc) * n, hipMemcpyHostToDevice, d->stream));
+    double bytes;
+    uint64_t mbs;
+    batch_cost(d, pics, n, bytes, mbs);
+    return launch_recon(d, d->d_desc_ring + at, n, bytes, mbs);
+}
+
+int leon_submit_picture(leon_decoder* d, const leon_picture* pic)
+{
+    if (!d || !pic) return fail(LEON_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(d->dev));
+    int rc = check_pic(d, *pic);
+    if (rc != LEON_OK) return rc;
+    Staging& s = d->stages[d->next_stage];
+    d->next_stage = (d->next_stage + 1) % leon_decoder::kStages;
+    if (!s.base) {
+        HIP_TRY(hipMalloc(&s.base, d->stage_bytes));
+        HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
+    }
+    if (s.busy) HIP_TRY(hipEventSynchronize(s.done));
+    const Geom& G = d->geom;
+    size_t ny = (size_t)G.cw * G.ch, nc = ny >> 2, mbs = (size_t)G.mbw * G.mbh;
+    size_t mpad = (mbs + 255) / 256 * 256, vpad = (mbs * 4 + 255) / 256 * 256;
+    char* p = s.base;
+    leon_picture dp = *pic;
+    auto put = [&](const void* src, size_t bytes, size_t reserve) -> const void* {
+        char* at = p;
+        p += reserve;
+        if (src) hipMemcpyAsync(at, src, bytes, hipMemcpyHostToDevice, d->stream);
+        return src ? at : nullptr;
+    };
+    dp.coef_y = (const int16_t*)put(pic->coef_y, ny * 2, ny * 2);
+    dp.coef_cb = (const int16_t*)put(pic->coef_cb, nc * 2, nc * 2);
+    dp.coef_cr = (const int16_t*)put(pic->coef_cr, nc * 2, nc * 2);
+    dp.qscale = (const uint8_t*)put(pic->qscale, mbs, mpad);
+    dp.intra = (const uint8_t*)put(pic->intra, mbs, mpad);
+    dp.repadd = (const uint8_t*)put(pic->type != LEON_PIC_I ? pic->repadd : nullptr, mbs, mpad);
+    dp.mb_dir = (const uint8_t*)put(pic->type == LEON_PIC_B ? pic->mb_dir : nullptr, mbs, mpad);
+    dp.mv_fwd = (const int16_t*)put(pic->type != LEON_PIC_I ? pic->mv_fwd : nullptr, mbs * 4, vpad);
+    dp.mv_bwd = (const int16_t*)put(pic->type == LEON_PIC_B ? pic->mv_bwd : nullptr, mbs * 4, vpad);
+    HIP_TRY(hipGetLastError());
+    int at = 0;
+    rc = reserve_descs(d, 1, at);
+    if (rc != LEON_OK) return rc;
+    fill_desc(d, dp, d->h_desc_pinned[at]);
+    HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc), hipMemcpyHostToDevice, d->stream));
+    double bytes;
+    uint64_t nmb;
+    batch_cost(d, pic, 1, bytes, nmb);
+    rc = launch_recon(d, d->d_desc_ring + at, 1, bytes, nmb);
+    if (rc != LEON_OK) return rc;
+    HIP_TRY(hipEventRecord(s.done, d->stream));
+    s.busy = true;
+    return LEON_OK;
+}
+
+int leon_batch_create(leon_decoder* d, const leon_picture* pics, int32_t n, leon_batch** out)
+{
+    if (!d || !pics || n <= 0 || !out) return fail(LEON_ERR_INVALID, "bad batch");
+    HIP_TRY(hipSetDevice(d->dev));
+    *out = nullptr;
+    std::vector<PicDesc> h(n);
+    for (int i = 0; i < n; i++) {
+        int rc = check_pic(d, pics[i]);
+        if (rc != LEON_OK) return rc;
+        fill_desc(d, pics[i], h[i]);
+    }
+    leon_batch* b = new (std::nothrow) leon_batch();
+    if (!b) return fail(LEON_ERR_NOMEM, "out of host memory");
+    b->n = n;
+    batch_cost(d, pics, n, b->bytes, b->mbs);
+    if (hipMalloc(&b->d_descs, sizeof(PicDesc) * n) != hipSuccess) {
+        delete b;
+        return fail(LEON_ERR_NOMEM, "descriptor allocation failed");
+    }
+    hipError_t e = hipMemcpy(b->d_descs, h.data(), sizeof(PicDesc) * n, hipMemcpyHostToDevice);
+    if (e != hipSuccess) {
+        hipFree(b->d_descs);
+        delete b;
+        return fail(LEON_ERR_HIP, "descriptor upload: %s", hipGetErrorString(e));
+    }
+    *out = b;
+    return LEON_OK;
+}
+
+int leon_batch_run(leon_decoder* d, const leon_batch* b)
+{
+    if (!d || !b) return fail(LEON_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(d->dev));
+    return launch_recon(d, b->d_descs, b->n, b->bytes, b->mbs);
+}
+
+void leon_batch_destroy(leon_decoder* d, leon_batch* b)
+{
+    if (!b) return;
+    if (d) {
+        hipSetDevice(d->dev);
+        hipStreamSynchronize(d->stream);
+    }
+    if (b->d_descs) hipFree(b->d_descs);
+    delete b;
+}
+
+int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, void* rgba_device, int32_t flavour)
+{
+    if (!d || !slots || n <= 0 || !rgba_device) return fail(LEON_ERR_INVALID, "bad argument");
+    if (flavour != LEON_RGB_CPU_TWIN && flavour != LEON_RGB_GL) return fail(LEON_ERR_INVALID, "flavour %d", flavour);
+    if (n > leon_decoder::kSlotIdRing) return fail(LEON_ERR_INVALID, "more than %d frames in one conversion", leon_decoder::kSlotIdRing);
+    HIP_TRY(hipSetDevice(d->dev));
+    for (int i = 0; i < n; i++)
+        if (slots[i] < 0 || slots[i] >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "slot %d", slots[i]);
+    if (d->slot_id_head + n > leon_decoder::kSlotIdRing) {
+        HIP_TRY(hipStreamSynchronize(d->stream));
+        d->slot_id_head = 0;
+    }
+    int at = d->slot_id_head;
+    d->slot_id_head += n;
+    memcpy(d->h_slot_ids + at, slots, sizeof(int32_t) * n);
+    HIP_TRY(hipMemcpyAsync(d->d_slot_ids + at, d->h_slot_ids + at, sizeof(int32_t) * n, hipMemcpyHostToDevice, d->stream));
+    RgbaGeom G{};
+    G.cw = d->cfg.coded_width;
+    G.ch = d->cfg.coded_height;
+    G.fw = d->cfg.frame_width;
+    G.fh = d->cfg.frame_height;
+    G.cols = G.fw >> 1;
+    G.rows = G.fh >> 1;
+    G.n = n;
+    G.flavour = flavour;
+    G.slot_stride_lo = (uint32_t)(d->slot_stride & 0xffffffffu);
+    G.slot_stride_hi = (uint32_t)(d->slot_stride >> 32);
+    TimedLaunch tl{};
+    if (d->timing) {
+        tl.a = get_event(d);
+        tl.b = get_event(d);
+        tl.kind = 1;
+        tl.mbs = (uint64_t)d->geom.mbw * d->geom.mbh * n;
+        tl.bytes = kRgbaBytesPerMb * (double)tl.mbs;
+        HIP_TRY(hipEventRecord(tl.a, d->stream));
+    }
+    if (flavour == LEON_RGB_CPU_TWIN) {
+        if ((G.fw & 1) || (G.fh & 1)) {   // bytes the quad loop never reaches stay 255 (fillArray)
+            size_t nd = (size_t)G.fw * G.fh * n;
+            hipLaunchKernelGGL(k_fill255, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, d->stream, (uint32_t*)rgba_device, nd);
+        }
+        if (G.cols > 0 && G.rows > 0)
+            hipLaunchKernelGGL(k_rgba_twin, dim3((G.cols + 255) / 256, G.rows, n), dim3(256), 0, d->stream,
+                               d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
+    } else {
+        hipLaunchKernelGGL(k_rgba_gl, dim3((G.fw + 255) / 256, G.fh, n), dim3(256), 0, d->stream,
+                           d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
+    }
+    HIP_TRY(hipGetLastError());
+    if (d->timing) {
+        HIP_TRY(hipEventRecord(tl.b, d->stream));
+        d->timed.push_back(tl);
+    }
+    return LEON_OK;
+}
+
+int leon_convert_rgba(leon_decoder* d, int32_t slot, void* rgba, int32_t dst_mem, int32_t flavour)
+{
+    if (!d || !rgba) return fail(LEON_ERR_INVALID, "null argument");
+    if (dst_mem == LEON_MEM_DEVICE) return leon_convert_rgba_batch(d, &slot, 1, rgba, flavour);
+    HIP_TRY(hipSetDevice(d->dev));
+    size_t bytes = (size_t)d->cfg.frame_width * d->cfg.frame_height * 4;
+    if (!d->d_rgba_tmp) HIP_TRY(hipMalloc(&d->d_rgba_tmp, bytes));
+    int rc = leon_convert_rgba_batch(d, &slot, 1, d->d_rgba_tmp, flavour);
+    if (rc != LEON_OK) return rc;
+    HIP_TRY(hipMemcpyAsync(rgba, d->d_rgba_tmp, bytes, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LEON_OK;
+}
+
+int leon_read_planes(leon_decoder* d, int32_t slot, uint8_t* y, uint8_t* cb, uint8_t* cr)
+{
+    if (!d || slot < 0 || slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "slot %d", slot);
+    HIP_TRY(hipSetDevice(d->dev));
+    size_t ny = (size_t)d->geom.cw * d->geom.ch, nc = ny >> 2;
+    const uint8_t* base = d->d_slots + (size_t)slot * d->slot_stride;
+    if (y) HIP_TRY(hipMemcpyAsync(y, base, ny, hipMemcpyDeviceToHost, d->stream));
+    if (cb) HIP_TRY(hipMemcpyAsync(cb, base + ny, nc, hipMemcpyDeviceToHost, d->stream));
+    if (cr) HIP_TRY(hipMemcpyAsync(cr, base + ny + nc, nc, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LEON_OK;
+}
+
+int leon_write_planes(leon_decoder* d, int32_t slot, const uint8_t* y, const uint8_t* cb, const uint8_t* cr)
+{
+    if (!d || slot < 0 || slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "slot %d", slot);
+    HIP_TRY(hipSetDevice(d->dev));
+    size_t ny = (size_t)d->geom.cw * d->geom.ch, nc = ny >> 2;
+    uint8_t* base = d->d_slots + (size_t)slot * d->slot_stride;
+    if (y) HIP_TRY(hipMemcpyAsync(base, y, ny, hipMemcpyHostToDevice, d->stream));
+    if (cb) HIP_TRY(hipMemcpyAsync(base + ny, cb, nc, hipMemcpyHostToDevice, d->stream));
+    if (cr) HIP_TRY(hipMemcpyAsync(base + ny + nc, cr, nc, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LEON_OK;
+}
+
+int leon_slot_device_ptr(leon_decoder* d, int32_t slot, void** ptr, size_t* bytes)
+{
+    if (!d || slot < 0 || slot >= d->cfg.n_slots || !ptr) return fail(LEON_ERR_INVALID, "slot %d", slot);
+    *ptr = d->d_slots + (size_t)slot * d->slot_stride;
+    if (bytes) *bytes = d->plane_bytes;
+    return LEON_OK;
+}
+
+int leon_sync(leon_decoder* d)
+{
+    if (!d) return fail(LEON_ERR_INVALID, "null decoder");
+    HIP_TRY(hipSetDevice(d->dev));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LEON_OK;
+}
+
+int leon_timing_enable(leon_decoder* d, int32_t on)
+{
+    if (!d) return fail(LEON_ERR_INVALID, "null decoder");
+    d->timing = on != 0;
+    return LEON_OK;
+}
+
+int leon_timing_reset(leon_decoder* d)
+{
+    if (!d) return fail(LEON_ERR_INVALID, "null decoder");
+    HIP_TRY(hipSetDevice(d->dev));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    for (auto& t : d->timed) {
+        d->ev_pool.push_back(t.a);
+        d->ev_pool.push_back(t.b);
+    }
+    d->timed.clear();
+    return LEON_OK;
+}
+
+int leon_timing_get(leon_decoder* d, int32_t kind, leon_kernel_stats* out)
+{
+    if (!d || !out) return fail(LEON_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(d->dev));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    leon_kernel_stats s{};
+    for (auto& t : d->timed) {
+        if (t.kind != kind) continue;
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
+        s.launches++;
+        s.total_ms += ms;
+        s.algorithmic_bytes += t.bytes;
+        s.macroblocks += t.mbs;
+    }
+    *out = s;
+    return LEON_OK;
+}
+
+int leon_measure_copy_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, double* gbps)
+{
+    if (!d || !gbps || bytes < 4096 || iters < 1) return fail(LEON_ERR_INVALID, "bad argument");
+    HIP_TRY(hipSetDevice(d->dev));
+    bytes &= ~(size_t)4095;
+    uint4 *src = nullptr, *dst = nullptr;
+    if (hipMalloc(&src, bytes) != hipSuccess) return fail(LEON_ERR_NOMEM, "copy source");
+    if (hipMalloc(&dst, bytes) != hipSuccess) {
+        hipFree(src);
+        return fail(LEON_ERR_NOMEM, "copy destination");
+    }
+    hipMemsetAsync(src, 0x5a, bytes, d->stream);
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    size_t n = bytes / 16;
+    int grid = 256 * 8;
+    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, d->stream, src, dst, n);   // warm-up
+    hipEventRecord(a, d->stream);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, d->stream, src, dst, n);
+    hipEventRecord(b, d->stream);
+    hipError_t e = hipStreamSynchronize(d->stream);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    hipFree(src);
+    hipFree(dst);
+    if (e != hipSuccess) return fail(LEON_ERR_HIP, "copy kernel: %s", hipGetErrorString(e));
+    *gbps = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
+    return LEON_OK;
+}
+
+}  // extern "C"

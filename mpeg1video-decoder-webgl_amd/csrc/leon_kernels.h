@@ -1,0 +1,532 @@
+// leon_kernels.h -- CDNA4 (gfx950) device code of the macroblock-reconstruction path.
+//
+// Three kernels, all HBM-bound integer/byte work (no MFMA: there is no dense
+// contraction in this path):
+//   k_recon      dequant + 8x8 IDCT (two passes with the reference's x0.4 int16
+//                hand-off) + forward/backward/bidirectional half-pel motion
+//                compensation + residual add + clamp, fused, for a BATCH of
+//                mutually independent pictures.            (K1a+K1b+K2+K2-B)
+//   k_rgba       YCbCr 4:2:0 -> RGBA8, fp64 "CPU twin" or fp32 "GL" flavour. (K3)
+//   k_copy16     streaming 16 B/lane copy = the measured HBM roofline.
+//
+// What the arithmetic follows in /root/reference:
+//   dequant + column pass   decoders/shaders/mpeg1video.js:19-24 (COL_INT_3, COL_INT_5)
+//   row pass + MC + clamp   decoders/shaders/mpeg1video.js:24-29 (ROWSCOM_INT4, INTER_INT1)
+//   predictor arithmetic    decoders/jsv.js:895-1129 (copyMacroblock), texel-granular
+//                           CLAMP_TO_EDGE of jsv.js:216-217
+//   colour conversion       player/easybits.player.js:2674-2785, player/parts/end.js:77-156
+//
+// Work decomposition of k_recon: one 64-lane wave = one "block group" = 8
+// horizontally adjacent 8x8 blocks of one plane (64 x 8 samples).  Waves never
+// talk to each other (no __syncthreads); each owns a private LDS strip.
+//   stage 1  lane (r,b): 16-byte load of coefficient row r of block b  -> LDS tile
+//            (8 rows x 128 B: every load instruction covers 8 full 128-B lines)
+//   stage 2  lane (b,c): column c of block b: 8 LDS reads, dequant, butterfly,
+//            floor(v*0.4f), int16 hand-off written transposed to LDS
+//   stage 3  lane (b,n): row n of block b: one 16-byte LDS read, trunc(5w/2),
+//            butterfly, (t+128)/256
+//   stage 4  lane (b,n): 8 predicted samples from the reference plane(s) via
+//            dword loads + v_alignbyte + v_lerp_u8, add, clamp, one 8-byte store
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace leon {
+
+struct PicDesc {                 // one per picture of a batch, device resident
+    const int16_t* coef[3];      // T1: Y, Cb, Cr raw levels
+    const uint8_t* qscale;       // T2
+    const uint8_t* intra;        // T3
+    const uint8_t* repadd;       // T4
+    const uint8_t* mb_dir;       // B only
+    const int16_t* mv_fwd;       // T5
+    const int16_t* mv_bwd;       // B only
+    uint8_t*       out;          // slot base: [Y | Cb | Cr]
+    const uint8_t* ref_fwd;
+    const uint8_t* ref_bwd;
+    int32_t        type;         // 1 I, 2 P, 3 B
+    int32_t        pad_;
+};
+
+struct Geom {
+    int32_t cw, ch;              // coded luma size
+    int32_t mbw, mbh;
+    int32_t gY, gC;              // block groups per block row (luma, chroma)
+    int32_t tasksY, tasksC;      // gY*(ch/8), gC*(ch/16)
+    int32_t tasks_per_pic;       // tasksY + 2*tasksC
+    int32_t n_pics;
+    int32_t n_wg;                // grid size (4 waves per workgroup)
+    int32_t pad_;
+};
+
+struct Tables {                  // T6, transposed so a lane reads its column as 8 bytes
+    uint8_t qmT[2][8][8];        // [0]=intra [1]=non-intra, [column c][row i]
+    uint8_t pmT[8][8];           // [column c][row i]
+};
+
+static constexpr int kWavesPerWG = 4;
+static constexpr int kLdsCoef = 1024;            // 8 rows x 128 B
+static constexpr int kLdsHandoffPitch = 144;     // 8 rows x 16 B + 16 B skew per block
+static constexpr int kLdsHandoff = 8 * kLdsHandoffPitch;
+static constexpr int kLdsPerWave = kLdsCoef + kLdsHandoff;
+
+// ---- small integer helpers -------------------------------------------------
+
+// Pointers read out of a PicDesc are generic; telling the compiler they are global
+// turns flat_load/flat_store into global_load/global_store with an SGPR base.
+#define LEON_GLOBAL __attribute__((address_space(1)))
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+template <typename T>
+__device__ __forceinline__ const LEON_GLOBAL T* gptr(const T* p) { return (const LEON_GLOBAL T*)p; }
+template <typename T>
+__device__ __forceinline__ LEON_GLOBAL T* gptr_mut(T* p) { return (LEON_GLOBAL T*)p; }
+
+// a*K + c with a 24-bit multiplier, one full-rate VALU op.  (hipcc turns __mul24 by
+// a constant into the quarter-rate v_mul_lo_u32 once it has proven the operand small.)
+__device__ __forceinline__ int mad24k(int a, int k, int c)
+{
+    int d;
+    asm("v_mad_i32_i24 %0, %1, %2, %3" : "=v"(d) : "v"(a), "s"(k), "v"(c));
+    return d;
+}
+
+// {sat_u8(a >> sh), sat_u8(b >> sh)} in the low 16 bits (gfx950 v_ashr_pk_u8_i32).
+// Always through the builtin: hipcc's own pattern match of med3(ashr)|shl onto this
+// instruction (ROCm 7.2) forgets that the instruction leaves the upper 16 destination
+// bits alone, which corrupted bytes 2..3 of the packed result for negative inputs.
+__device__ __forceinline__ uint32_t sat_pk2(int a, int b, uint32_t sh)
+{
+    return (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(a, b, sh) & 0xffffu;
+}
+
+// GLSL int '/' 256 (truncation toward zero), 3 VALU ops
+__device__ __forceinline__ int div256(int t)
+{
+    return (int)(__umul24((unsigned)t >> 31, 255u) + (unsigned)t) >> 8;
+}
+
+__device__ __forceinline__ int med3i(int v, int lo, int hi) { return min(max(v, lo), hi); }
+
+// mpeg1video.js:23 / :26.  BIAS is added to X[0] (every output contains +m0 once).
+__device__ __forceinline__ void butterfly8(const int (&X)[8], int (&o)[8])
+{
+    int b1 = X[4];
+    int b3 = X[2] + X[6];
+    int b4 = X[5] - X[3];
+    int tmp1 = X[1] + X[7];
+    int tmp2 = X[3] + X[5];
+    int b6 = X[1] - X[7];
+    int b7 = tmp1 + tmp2;
+    int m0 = X[0];
+    const int c128 = 128;
+    int x4 = div256(mad24k(b6, 473, mad24k(b4, -196, c128))) - b7;
+    int x0 = x4 - div256(mad24k(tmp1 - tmp2, 362, c128));
+    int x1 = m0 - b1;
+    int x2 = div256(mad24k(X[2] - X[6], 362, c128)) - b3;
+    int x3 = m0 + b1;
+    int y3 = x1 + x2;
+    int y4 = x3 + b3;
+    int y5 = x1 - x2;
+    int y6 = x3 - b3;
+    int y7 = -x0 - div256(mad24k(b4, 473, mad24k(b6, 196, c128)));
+    o[0] = b7 + y4;
+    o[1] = x4 + y3;
+    o[2] = y5 - x0;
+    o[3] = y6 - y7;
+    o[4] = y6 + y7;
+    o[5] = x0 + y5;
+    o[6] = y3 - x4;
+    o[7] = y4 - b7;
+}
+
+// COL_INT_3: one coefficient.  qO = quantiser_scale * matrix entry, pm = premultiplier.
+__device__ __forceinline__ int dequant1(int X, int qO, int pm, int nonintra_mask)
+{
+    int s = X >> 31;                                  // -1 / 0
+    int x2 = 2 * X + ((s | 1) & nonintra_mask);       // X*2, += sign for non-intra
+    int t = __mul24(x2, qO);                          // |x2| < 2^17, qO < 2^13
+    int f = t >> 4;                                   // floor(./16)
+    f = (f - (f > 0 ? 1 : 0)) | 1;                    // even -> toward zero; 0 -> +1
+    f = med3i(f, -2048, 2047);
+    int r = __mul24(f, pm);
+    return X == 0 ? 0 : r;                            // zeros are skipped
+}
+
+// _B()/_E() int16 hand-off incl. UNORM8 saturation of the high byte (mpeg1video.js:18)
+__device__ __forceinline__ int handoff16(int w)
+{
+    int r = (int)(short)w;                            // |w| < 65536: w mod 2^16
+    if (w >= 65536) r = (w & 255) - 256;              // hi byte saturates at 255
+    if (w < -65536) r = w & 255;                      // hi byte saturates at 0
+    return r;
+}
+
+// ---- motion-compensated prediction of 8 horizontally adjacent samples ------
+
+// exact (a+b+c+d+2)>>2 on 4 packed bytes: three rounded-up averages and one fix-up
+__device__ __forceinline__ uint32_t avg4_u8x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
+{
+    const uint32_t ones = 0x01010101u;
+    uint32_t x = __builtin_amdgcn_lerp(a, b, ones);
+    uint32_t y = __builtin_amdgcn_lerp(c, d, ones);
+    uint32_t r = __builtin_amdgcn_lerp(x, y, ones);
+    return r - (((a ^ b) | (c ^ d)) & (x ^ y) & ones);
+}
+
+// reference texel addressing: sample x lives in RGBA texel x>>2, component x&3; the
+// TEXEL index clamps to the edge (jsv.js:216-217 + _p() mpeg1video.js:24)
+__device__ __forceinline__ uint32_t ref_px_clamped(const LEON_GLOBAL uint8_t* ref, uint32_t row_off, int W, int x)
+{
+    int t = min(max(x >> 2, 0), (W >> 2) - 1);
+    return ref[row_off + (uint32_t)(4 * t + (x & 3))];
+}
+
+// 9 samples px..px+8 of one row, for vectors that leave the picture (rare, divergent)
+__device__ __forceinline__ void gather9_slow(const LEON_GLOBAL uint8_t* ref, uint32_t row_off, int W, int px,
+                                             uint32_t& a0, uint32_t& a1, uint32_t& a2)
+{
+    uint32_t lo = 0, hi = 0;
+#pragma unroll 1
+    for (int k = 0; k < 4; k++) {
+        lo |= ref_px_clamped(ref, row_off, W, px + k) << (8 * k);
+        hi |= ref_px_clamped(ref, row_off, W, px + 4 + k) << (8 * k);
+    }
+    a0 = lo;
+    a1 = hi;
+    a2 = ref_px_clamped(ref, row_off, W, px + 8);
+}
+
+// 8 predicted samples at (x0..x0+7, y) of one plane for vector (mh, mv) in luma
+// half-pel units.  CHROMA: vector is truncated toward zero first (mv_coef 0.5).
+// `ref` is the plane base (wave-uniform), offsets are 32-bit.
+template <bool CHROMA>
+__device__ __forceinline__ uint2 predict8(const LEON_GLOBAL uint8_t* ref, int W, int H,
+                                          int x0, int y, int mh, int mv)
+{
+    int h = CHROMA ? mh / 2 : mh;
+    int v = CHROMA ? mv / 2 : mv;
+    int ax = h >> 1, ay = v >> 1;
+    uint32_t oh = h & 1, ov = v & 1;
+    int px = x0 + ax;
+    int py0 = min(max(y + ay, 0), H - 1);
+    int py1 = min(max(y + ay + (int)ov, 0), H - 1);
+    uint32_t r0 = (uint32_t)__mul24(py0, W);
+    uint32_t r1 = (uint32_t)__mul24(py1, W);
+    uint32_t a0, a1, a2, c0, c1, c2;
+    if (px >= 0 && px + 7 + (int)oh <= W - 1) {
+        uint32_t s = px & 3;
+        uint32_t xo = (uint32_t)(px & ~3);
+        const LEON_GLOBAL uint32_t* q0 = (const LEON_GLOBAL uint32_t*)(ref + (r0 + xo));
+        const LEON_GLOBAL uint32_t* q1 = (const LEON_GLOBAL uint32_t*)(ref + (r1 + xo));
+        uint32_t l0 = q0[0], l1 = q0[1], l2 = q0[2];
+        uint32_t m0 = q1[0], m1 = q1[1], m2 = q1[2];
+        a0 = __builtin_amdgcn_alignbyte(l1, l0, s);
+        a1 = __builtin_amdgcn_alignbyte(l2, l1, s);
+        a2 = __builtin_amdgcn_alignbyte(0u, l2, s);
+        c0 = __builtin_amdgcn_alignbyte(m1, m0, s);
+        c1 = __builtin_amdgcn_alignbyte(m2, m1, s);
+        c2 = __builtin_amdgcn_alignbyte(0u, m2, s);
+    } else {                                         // vector leaves the picture (rare)
+        gather9_slow(ref, r0, W, px, a0, a1, a2);
+        gather9_slow(ref, r1, W, px, c0, c1, c2);
+    }
+    // horizontal neighbour = same bytes shifted by oh (0 or 1)
+    uint32_t b0 = __builtin_amdgcn_alignbyte(a1, a0, oh);
+    uint32_t b1 = __builtin_amdgcn_alignbyte(a2, a1, oh);
+    uint32_t d0 = __builtin_amdgcn_alignbyte(c1, c0, oh);
+    uint32_t d1 = __builtin_amdgcn_alignbyte(c2, c1, oh);
+    uint2 p;
+    p.x = avg4_u8x4(a0, b0, c0, d0);
+    p.y = avg4_u8x4(a1, b1, c1, d1);
+    return p;
+}
+
+// byte m of `pred` moved to bits 8..15 (so that it adds as pred*256), one v_perm_b32
+template <int M>
+__device__ __forceinline__ uint32_t pred_x256(uint32_t pred)
+{
+    // selector bytes: 0x0c = constant 0x00; 0..3 pick bytes of the second operand
+    return __builtin_amdgcn_perm(0u, pred, 0x0c0c000cu | ((uint32_t)M << 8));
+}
+
+// ---- one block group ------------------------------------------------------------
+
+template <int TYPE, bool CHROMA>
+__device__ __forceinline__ void recon_group(const PicDesc& pd, const Geom& G, const Tables* __restrict__ Tg,
+                                            int comp, int R, int g, char* lds, int lane)
+{
+    const int W = CHROMA ? G.cw >> 1 : G.cw;
+    const int H = CHROMA ? G.ch >> 1 : G.ch;
+    const int bw = W >> 3;
+    const uint32_t ysz = (uint32_t)G.cw * (uint32_t)G.ch;
+    const uint32_t plane_off = comp == 0 ? 0u : (comp == 1 ? ysz : ysz + (ysz >> 2));
+    const LEON_GLOBAL int16_t* coef = gptr(pd.coef[comp]);
+    const LEON_GLOBAL Tables* T = gptr(Tg);
+
+    // ---- stage 1: coefficient rows -> LDS tile [r][b][c] -----------------------
+    {
+        int r = lane >> 3, b = lane & 7;
+        int Q = g * 8 + b;
+        v4i v = {0, 0, 0, 0};
+        if (Q < bw)
+            v = *(const LEON_GLOBAL v4i*)(coef + ((uint32_t)__mul24(8 * R + r, W) + (uint32_t)(8 * Q)));
+        *reinterpret_cast<v4i*>(lds + r * 128 + b * 16) = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    const int b = lane >> 3;
+    const int Qb = g * 8 + b;
+    const bool valid = Qb < bw;
+    const int Qs = valid ? Qb : bw - 1;
+    const uint32_t mb = (uint32_t)(CHROMA ? R * G.mbw + Qs : (R >> 1) * G.mbw + (Qs >> 1));
+
+    // ---- stage 2: column pass --------------------------------------------------
+    {
+        int c = lane & 7;
+        int q = gptr(pd.qscale)[mb];
+        bool ia = gptr(pd.intra)[mb] != 0;                   // I pictures honour the map too (COL_3)
+        v2u qmc = *(const LEON_GLOBAL v2u*)(&T->qmT[ia ? 0 : 1][c][0]);
+        v2u pmc = *(const LEON_GLOBAL v2u*)(&T->pmT[c][0]);
+        int nim = ia ? 0 : -1;
+        int X[8], v[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+            X[i] = *reinterpret_cast<const short*>(lds + i * 128 + b * 16 + c * 2);
+        int dc = X[0];
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            uint32_t Ow = i < 4 ? qmc.x : qmc.y, Pw = i < 4 ? pmc.x : pmc.y;
+            int O = (Ow >> (8 * (i & 3))) & 255;
+            int P = (Pw >> (8 * (i & 3))) & 255;
+            X[i] = dequant1(X[i], __mul24(q, O), P, nim);
+        }
+        if (c == 0 && ia) X[0] = dc * 256;            // COL_4 / COL_INT_31
+        butterfly8(X, v);
+        char* hp = lds + kLdsCoef + b * kLdsHandoffPitch + c * 2;
+#pragma unroll
+        for (int n = 0; n < 8; n++) {
+            int w = (int)floorf((float)v[n] * 0.4f);  // floor( float(v) * _y )
+            *reinterpret_cast<short*>(hp + n * 16) = (short)handoff16(w);
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+    // ---- stage 3: row pass -----------------------------------------------------
+    const int n = lane & 7;
+    int t[8];
+    {
+        int4 wv = *reinterpret_cast<const int4*>(lds + kLdsCoef + b * kLdsHandoffPitch + n * 16);
+        int X[8];
+        const int ww[4] = {wv.x, wv.y, wv.z, wv.w};
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            int w0 = (int)(short)(ww[k] & 0xffff), w1 = ww[k] >> 16;
+            // int( w / 0.4f ) == trunc(5w/2) for every int16 w (tests/test_identities.py)
+            X[2 * k] = (5 * w0 + (int)((unsigned)w0 >> 31)) >> 1;
+            X[2 * k + 1] = (5 * w1 + (int)((unsigned)w1 >> 31)) >> 1;
+        }
+        X[0] += 128;                                  // the "+128" of (t+128)/256
+        butterfly8(X, t);
+        // (t/256 truncating) as an arithmetic shift: add 255 to negative values first
+#pragma unroll
+        for (int m = 0; m < 8; m++) t[m] += (t[m] >> 31) & 255;
+    }
+
+    // ---- stage 4: prediction, add, clamp, store ---------------------------------
+    const int y = 8 * R + n;
+    const int x0 = 8 * Qs;
+    if (TYPE != 1) {
+        uint2 pred = make_uint2(0u, 0u);
+        const bool rep = gptr(pd.repadd)[mb] >= 128;                  // .r > 0.5
+        const uint32_t mf = *(const LEON_GLOBAL uint32_t*)(gptr(pd.mv_fwd) + 2 * mb);
+        const int fh = (int)(short)(mf & 0xffff), fv = (int)mf >> 16;
+        if (TYPE == 2) {
+            pred = predict8<CHROMA>(gptr(pd.ref_fwd) + plane_off, W, H, x0, y, fh, fv);
+        } else {
+            const uint32_t mbk = *(const LEON_GLOBAL uint32_t*)(gptr(pd.mv_bwd) + 2 * mb);
+            const int bh = (int)(short)(mbk & 0xffff), bv = (int)mbk >> 16;
+            const int dir = gptr(pd.mb_dir)[mb] & 3;
+            // a missing direction re-uses the other one: (p + p + 1) >> 1 == p
+            const bool usef = (dir & 1) != 0;
+            const bool useb = (dir & 2) != 0;
+            const LEON_GLOBAL uint8_t* rfw = gptr(pd.ref_fwd) + plane_off;
+            const LEON_GLOBAL uint8_t* rbw = gptr(pd.ref_bwd) + plane_off;
+            uint2 pf = predict8<CHROMA>(usef ? rfw : rbw, W, H, x0, y, usef ? fh : bh, usef ? fv : bv);
+            uint2 pb = predict8<CHROMA>(useb ? rbw : rfw, W, H, x0, y, useb ? bh : fh, useb ? bv : fv);
+            pred.x = __builtin_amdgcn_lerp(pf.x, pb.x, 0x01010101u);
+            pred.y = __builtin_amdgcn_lerp(pf.y, pb.y, 0x01010101u);
+            if (dir == 0) pred = make_uint2(0u, 0u);
+        }
+        if (rep) pred = make_uint2(0u, 0u);
+        // clamp(t/256 + pred) == sat_u8((t + pred*256) >> 8)
+        t[0] += pred_x256<0>(pred.x);
+        t[1] += pred_x256<1>(pred.x);
+        t[2] += pred_x256<2>(pred.x);
+        t[3] += pred_x256<3>(pred.x);
+        t[4] += pred_x256<0>(pred.y);
+        t[5] += pred_x256<1>(pred.y);
+        t[6] += pred_x256<2>(pred.y);
+        t[7] += pred_x256<3>(pred.y);
+    }
+    v2u o;
+    o.x = sat_pk2(t[0], t[1], 8) | (sat_pk2(t[2], t[3], 8) << 16);
+    o.y = sat_pk2(t[4], t[5], 8) | (sat_pk2(t[6], t[7], 8) << 16);
+    if (valid)
+        *(LEON_GLOBAL v2u*)(gptr_mut(pd.out) + (plane_off + (uint32_t)__mul24(y, W) + (uint32_t)x0)) = o;
+}
+
+// XCD-aware workgroup remap: hardware deals workgroups round-robin over the 8 XCDs;
+// give each XCD one contiguous run of the task space so that vertically adjacent
+// block groups (which share reference lines) meet in the same L2.  Bijective for any n.
+__device__ __forceinline__ int xcd_remap(int bid, int n)
+{
+    int q = n >> 3, r = n & 7;
+    int x = bid & 7, j = bid >> 3;
+    return x * q + min(x, r) + j;
+}
+
+template <int TYPE>
+__device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G, const Tables* T,
+                                               int t, char* lds, int lane)
+{
+    if (t < G.tasksY) {
+        int R = t / G.gY, g = t - R * G.gY;
+        recon_group<TYPE, false>(pd, G, T, 0, R, g, lds, lane);
+    } else {
+        t -= G.tasksY;
+        int comp = 1;
+        if (t >= G.tasksC) { t -= G.tasksC; comp = 2; }
+        int R = t / G.gC, g = t - R * G.gC;
+        recon_group<TYPE, true>(pd, G, T, comp, R, g, lds, lane);
+    }
+}
+
+__global__ __launch_bounds__(256) void k_recon(const PicDesc* __restrict__ descs, Geom G,
+                                               const Tables* __restrict__ T)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wg = xcd_remap(blockIdx.x, G.n_wg);
+    const int task = wg * kWavesPerWG + wave;
+    const int pic = task / G.tasks_per_pic;
+    if (pic >= G.n_pics) return;
+    const int t = task - pic * G.tasks_per_pic;
+    char* lds = smem + wave * kLdsPerWave;
+    const PicDesc& pd = descs[pic];
+    const int type = pd.type;
+    if (type == 1) recon_dispatch<1>(pd, G, T, t, lds, lane);
+    else if (type == 2) recon_dispatch<2>(pd, G, T, t, lds, lane);
+    else recon_dispatch<3>(pd, G, T, t, lds, lane);
+}
+
+// ---- K3: YCbCr 4:2:0 -> RGBA8 ------------------------------------------------------
+
+struct RgbaGeom {
+    int32_t cw, ch, fw, fh;
+    int32_t cols, rows;          // fw>>1, fh>>1 quads
+    int32_t n;                   // frames in the batch
+    int32_t flavour;             // 0 CPU twin (fp64), 1 GL (fp32)
+    uint32_t slot_stride_lo, slot_stride_hi;   // bytes between slots
+};
+
+// Uint8ClampedArray store: clamp, round half to even (2^52+2^51 trick; |x| < 2^31)
+__device__ __forceinline__ uint32_t u8_clamped(double x)
+{
+    double t = x + 6755399441055744.0;
+    int i = __double2loint(t);
+    return (uint32_t)med3i(i, 0, 255);
+}
+
+// CPU twin, one thread per 2x2 quad, with the reference's flat index progression
+// (player/easybits.player.js:2692-2782): identical to a plain crop for even frame
+// widths, and reproducing its one-sample-per-row-pair drift for odd ones.
+__global__ __launch_bounds__(256) void k_rgba_twin(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
+                                                   uint8_t* __restrict__ rgba, RgbaGeom G)
+{
+    const int col = blockIdx.x * blockDim.x + threadIdx.x;
+    const int row = blockIdx.y;
+    const int f = blockIdx.z;
+    if (col >= G.cols) return;
+    const size_t stride = ((size_t)G.slot_stride_hi << 32) | G.slot_stride_lo;
+    const uint8_t* Y = slots + (size_t)slot_ids[f] * stride;
+    const uint8_t* Cb = Y + (size_t)G.cw * G.ch;
+    const uint8_t* Cr = Cb + ((size_t)G.cw * G.ch >> 2);
+    uint8_t* dst = rgba + (size_t)f * G.fw * G.fh * 4;
+    const int odd = G.fw & 1;
+    const int hw = G.cw >> 1;
+    const int yi1 = row * (2 * G.cw - odd) + 2 * col;
+    const int yi2 = yi1 + G.cw;
+    const int ci = row * hw + col;
+    const size_t d1 = 4 * ((size_t)row * (2 * G.fw - odd) + 2 * col);
+    const size_t d2 = d1 + 4 * (size_t)G.fw;
+    const double yuvr = (double)Cr[ci] - 128.0, yuvb = (double)Cb[ci] - 128.0;
+    const double r = yuvr * 1.59603;
+    const double g = (-0.81297 * yuvr) - (0.39176 * yuvb);
+    const double b = yuvb * 2.01723;
+    uint32_t px[4];
+    const int yidx[4] = {yi1, yi1 + 1, yi2, yi2 + 1};
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        double ys = ((double)Y[yidx[k]] - 16.0) * 1.16438;
+        px[k] = u8_clamped(r + ys) | (u8_clamped(g + ys) << 8) | (u8_clamped(b + ys) << 16) | 0xff000000u;
+    }
+    *reinterpret_cast<uint32_t*>(dst + d1) = px[0];
+    *reinterpret_cast<uint32_t*>(dst + d1 + 4) = px[1];
+    *reinterpret_cast<uint32_t*>(dst + d2) = px[2];
+    *reinterpret_cast<uint32_t*>(dst + d2 + 4) = px[3];
+}
+
+// fills what the quad loop never writes (odd last row / column, drift leftovers) with 255
+__global__ __launch_bounds__(256) void k_fill255(uint32_t* __restrict__ p, size_t n_dwords)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n_dwords) p[i] = 0xffffffffu;
+}
+
+// GL flavour: every pixel of the frame_w x frame_h crop, fp32, left-to-right, no contraction
+__global__ __launch_bounds__(256) void k_rgba_gl(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
+                                                 uint8_t* __restrict__ rgba, RgbaGeom G)
+{
+    const int x = blockIdx.x * blockDim.x + threadIdx.x;
+    const int yy = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= G.fw) return;
+    const size_t stride = ((size_t)G.slot_stride_hi << 32) | G.slot_stride_lo;
+    const uint8_t* Y = slots + (size_t)slot_ids[f] * stride;
+    const uint8_t* Cb = Y + (size_t)G.cw * G.ch;
+    const uint8_t* Cr = Cb + ((size_t)G.cw * G.ch >> 2);
+    const int hw = G.cw >> 1;
+    const float fy = (float)Y[(size_t)yy * G.cw + x] / 255.0f;
+    const float fcb = (float)Cb[(size_t)(yy >> 1) * hw + (x >> 1)] / 255.0f;
+    const float fcr = (float)Cr[(size_t)(yy >> 1) * hw + (x >> 1)] / 255.0f;
+    const float M[3][4] = {{1.16438f, 0.00000f, 1.59603f, -0.87079f},
+                           {1.16438f, -0.39176f, -0.81297f, 0.52959f},
+                           {1.16438f, 2.01723f, 0.00000f, -1.08139f}};
+    uint32_t o = 0xff000000u;
+#pragma unroll
+    for (int c = 0; c < 3; c++) {
+        float s = fy * M[c][0];
+        s = s + fcb * M[c][1];
+        s = s + fcr * M[c][2];
+        s = s + M[c][3];
+        s = fminf(fmaxf(s, 0.0f), 1.0f);
+        o |= (uint32_t)__float2int_rn(s * 255.0f) << (8 * c);
+    }
+    *reinterpret_cast<uint32_t*>(rgba + ((size_t)f * G.fw * G.fh + (size_t)yy * G.fw + x) * 4) = o;
+}
+
+// ---- measured HBM roofline -----------------------------------------------------------
+__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n)
+{
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * blockDim.x;
+    for (; i < n; i += step) dst[i] = src[i];
+}
+
+}  // namespace leon

@@ -1,0 +1,245 @@
+"""ctypes binding of libleon_hip.so (include/leon.h) for the Python-side plumbing:
+tests, bench.py and the multi-GPU launcher.  The product's host language is
+JavaScript (js/ + the N-API addon); this file only moves pointers around.
+
+Fails loudly when the library is missing or no gfx950 device is usable: there is
+no CPU fallback anywhere in this package.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.environ.get("LEON_LIB", os.path.join(_HERE, "lib", "libleon_hip.so"))
+
+OK = 0
+ERR_INVALID, ERR_NO_DEVICE, ERR_HIP, ERR_NO_FREE_SLOT, ERR_NOMEM = -1, -2, -3, -4, -5
+PIC_I, PIC_P, PIC_B = 1, 2, 3
+MEM_HOST, MEM_DEVICE = 0, 1
+RGB_CPU_TWIN, RGB_GL = 0, 1
+
+# every symbol include/leon.h declares (tests check the library exports all of them)
+SYMBOLS = [
+    "leon_abi_version", "leon_last_error", "leon_create", "leon_destroy", "leon_set_quant_matrices",
+    "leon_acquire_slot", "leon_release_slot", "leon_free_decoded_slots", "leon_submit_picture",
+    "leon_submit_batch", "leon_batch_create", "leon_batch_run", "leon_batch_destroy",
+    "leon_convert_rgba", "leon_convert_rgba_batch", "leon_read_planes", "leon_write_planes",
+    "leon_slot_device_ptr", "leon_sync", "leon_timing_enable", "leon_timing_reset", "leon_timing_get",
+    "leon_measure_copy_bandwidth",
+]
+
+
+class LeonError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("leon error %d: %s" % (code, msg))
+        self.code = code
+
+
+class Config(C.Structure):
+    _fields_ = [("coded_width", C.c_int32), ("coded_height", C.c_int32), ("frame_width", C.c_int32),
+                ("frame_height", C.c_int32), ("n_slots", C.c_int32), ("device_id", C.c_int32),
+                ("stream", C.c_void_p)]
+
+
+class Picture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("out_slot", C.c_int32), ("ref_fwd_slot", C.c_int32),
+                ("ref_bwd_slot", C.c_int32), ("coef_y", C.c_void_p), ("coef_cb", C.c_void_p),
+                ("coef_cr", C.c_void_p), ("qscale", C.c_void_p), ("intra", C.c_void_p),
+                ("repadd", C.c_void_p), ("mv_fwd", C.c_void_p), ("mv_bwd", C.c_void_p),
+                ("mb_dir", C.c_void_p)]
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double),
+                ("macroblocks", C.c_uint64)]
+
+
+_lib = None
+
+
+def load():
+    """dlopen the library (no GPU needed for this); raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    # torch ships its own libamdhip64.so.7; two HIP runtimes in one process cannot both
+    # own the GPU ("No HIP GPUs are available").  Whichever is loaded first serves both,
+    # so when torch is going to be used in this process let it load first.
+    if os.environ.get("LEON_NO_TORCH") != "1":
+        try:
+            import torch  # noqa: F401
+        except Exception:
+            pass
+    if not os.path.exists(LIB_PATH):
+        raise ImportError("libleon_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "or `make -C mpeg1video-decoder-webgl_amd/csrc` (no CPU fallback exists)")
+    lib = C.CDLL(LIB_PATH)
+    lib.leon_last_error.restype = C.c_char_p
+    lib.leon_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
+    lib.leon_destroy.argtypes = [C.c_void_p]
+    lib.leon_destroy.restype = None
+    lib.leon_set_quant_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.leon_acquire_slot.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+    lib.leon_release_slot.argtypes = [C.c_void_p, C.c_int32]
+    lib.leon_free_decoded_slots.argtypes = [C.c_void_p]
+    lib.leon_submit_picture.argtypes = [C.c_void_p, C.POINTER(Picture)]
+    lib.leon_submit_batch.argtypes = [C.c_void_p, C.POINTER(Picture), C.c_int32, C.c_int32]
+    lib.leon_batch_create.argtypes = [C.c_void_p, C.POINTER(Picture), C.c_int32, C.POINTER(C.c_void_p)]
+    lib.leon_batch_run.argtypes = [C.c_void_p, C.c_void_p]
+    lib.leon_batch_destroy.argtypes = [C.c_void_p, C.c_void_p]
+    lib.leon_batch_destroy.restype = None
+    lib.leon_convert_rgba.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32]
+    lib.leon_convert_rgba_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+    lib.leon_read_planes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.leon_write_planes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.leon_slot_device_ptr.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
+    lib.leon_sync.argtypes = [C.c_void_p]
+    lib.leon_timing_enable.argtypes = [C.c_void_p, C.c_int32]
+    lib.leon_timing_reset.argtypes = [C.c_void_p]
+    lib.leon_timing_get.argtypes = [C.c_void_p, C.c_int32, C.POINTER(KernelStats)]
+    lib.leon_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double)]
+    _lib = lib
+    return lib
+
+
+def _chk(rc):
+    if rc != OK:
+        raise LeonError(rc, load().leon_last_error().decode("utf-8", "replace"))
+
+
+def _hostptr(a, dtype, keep):
+    if a is None:
+        return None
+    a = np.ascontiguousarray(a, dtype=dtype)
+    keep.append(a)
+    return a.ctypes.data
+
+
+def make_picture(ptype, out_slot, coef_y, coef_cb, coef_cr, qscale, intra, repadd=None, mv_fwd=None,
+                 mv_bwd=None, mb_dir=None, ref_fwd_slot=-1, ref_bwd_slot=-1, keep=None, device=False):
+    """Fill a Picture from numpy arrays (host) or raw device addresses (device=True: ints)."""
+    p = Picture()
+    p.type, p.out_slot, p.ref_fwd_slot, p.ref_bwd_slot = ptype, out_slot, ref_fwd_slot, ref_bwd_slot
+    if device:
+        vals = (coef_y, coef_cb, coef_cr, qscale, intra, repadd, mv_fwd, mv_bwd, mb_dir)
+        (p.coef_y, p.coef_cb, p.coef_cr, p.qscale, p.intra, p.repadd, p.mv_fwd, p.mv_bwd, p.mb_dir) = \
+            [None if v is None else int(v) for v in vals]
+        return p
+    keep = keep if keep is not None else []
+    p.coef_y = _hostptr(coef_y, np.int16, keep)
+    p.coef_cb = _hostptr(coef_cb, np.int16, keep)
+    p.coef_cr = _hostptr(coef_cr, np.int16, keep)
+    p.qscale = _hostptr(qscale, np.uint8, keep)
+    p.intra = _hostptr(intra, np.uint8, keep)
+    p.repadd = _hostptr(repadd, np.uint8, keep)
+    p.mv_fwd = _hostptr(mv_fwd, np.int16, keep)
+    p.mv_bwd = _hostptr(mv_bwd, np.int16, keep)
+    p.mb_dir = _hostptr(mb_dir, np.uint8, keep)
+    p._keep = keep
+    return p
+
+
+class Decoder:
+    """Thin object wrapper over the C ABI; method names follow include/leon.h."""
+
+    def __init__(self, coded_w, coded_h, frame_w=None, frame_h=None, n_slots=13, device_id=0, stream=None):
+        self.lib = load()
+        cfg = Config(coded_w, coded_h, frame_w or coded_w, frame_h or coded_h, n_slots, device_id, stream)
+        h = C.c_void_p()
+        _chk(self.lib.leon_create(C.byref(cfg), C.byref(h)))
+        self.h = h
+        self.cw, self.ch = coded_w, coded_h
+        self.fw, self.fh = cfg.frame_width, cfg.frame_height
+        self.n_slots = n_slots
+
+    def close(self):
+        if self.h:
+            self.lib.leon_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_quant_matrices(self, intra=None, non_intra=None):
+        keep = []
+        _chk(self.lib.leon_set_quant_matrices(self.h, _hostptr(intra, np.uint8, keep), _hostptr(non_intra, np.uint8, keep)))
+
+    def acquire_slot(self):
+        s = C.c_int32()
+        _chk(self.lib.leon_acquire_slot(self.h, C.byref(s)))
+        return s.value
+
+    def release_slot(self, slot):
+        _chk(self.lib.leon_release_slot(self.h, slot))
+
+    def free_decoded_slots(self):
+        _chk(self.lib.leon_free_decoded_slots(self.h))
+
+    def submit_picture(self, pic):
+        _chk(self.lib.leon_submit_picture(self.h, C.byref(pic)))
+
+    def submit_batch(self, pics, mem=MEM_DEVICE):
+        arr = (Picture * len(pics))(*pics)
+        _chk(self.lib.leon_submit_batch(self.h, arr, len(pics), mem))
+
+    def batch_create(self, pics):
+        arr = (Picture * len(pics))(*pics)
+        b = C.c_void_p()
+        _chk(self.lib.leon_batch_create(self.h, arr, len(pics), C.byref(b)))
+        return b
+
+    def batch_run(self, b):
+        _chk(self.lib.leon_batch_run(self.h, b))
+
+    def batch_destroy(self, b):
+        self.lib.leon_batch_destroy(self.h, b)
+
+    def convert_rgba(self, slot, flavour=RGB_CPU_TWIN):
+        out = np.empty((self.fh, self.fw, 4), dtype=np.uint8)
+        _chk(self.lib.leon_convert_rgba(self.h, slot, out.ctypes.data, MEM_HOST, flavour))
+        return out
+
+    def convert_rgba_batch(self, slots, rgba_device_ptr, flavour=RGB_CPU_TWIN):
+        s = np.ascontiguousarray(slots, dtype=np.int32)
+        _chk(self.lib.leon_convert_rgba_batch(self.h, s.ctypes.data, len(s), int(rgba_device_ptr), flavour))
+
+    def read_planes(self, slot):
+        n = self.cw * self.ch
+        y = np.empty((self.ch, self.cw), dtype=np.uint8)
+        cb = np.empty((self.ch // 2, self.cw // 2), dtype=np.uint8)
+        cr = np.empty((self.ch // 2, self.cw // 2), dtype=np.uint8)
+        _chk(self.lib.leon_read_planes(self.h, slot, y.ctypes.data, cb.ctypes.data, cr.ctypes.data))
+        return y, cb, cr
+
+    def write_planes(self, slot, y, cb, cr):
+        keep = []
+        _chk(self.lib.leon_write_planes(self.h, slot, _hostptr(y, np.uint8, keep), _hostptr(cb, np.uint8, keep),
+                                        _hostptr(cr, np.uint8, keep)))
+
+    def slot_device_ptr(self, slot):
+        p, n = C.c_void_p(), C.c_size_t()
+        _chk(self.lib.leon_slot_device_ptr(self.h, slot, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def sync(self):
+        _chk(self.lib.leon_sync(self.h))
+
+    def timing_enable(self, on=True):
+        _chk(self.lib.leon_timing_enable(self.h, 1 if on else 0))
+
+    def timing_reset(self):
+        _chk(self.lib.leon_timing_reset(self.h))
+
+    def timing_get(self, kind=0):
+        s = KernelStats()
+        _chk(self.lib.leon_timing_get(self.h, kind, C.byref(s)))
+        return {"launches": s.launches, "total_ms": s.total_ms, "algorithmic_bytes": s.algorithmic_bytes,
+                "macroblocks": s.macroblocks}
+
+    def measure_copy_bandwidth(self, nbytes=1 << 31, iters=10):
+        g = C.c_double()
+        _chk(self.lib.leon_measure_copy_bandwidth(self.h, nbytes, iters, C.byref(g)))
+        return g.value

@@ -1,0 +1,44 @@
+"""Shared test plumbing: run the same boundary tensors through the oracle (CPU) and
+through libleon_hip.so (C ABI, GPU) and compare planes bit for bit."""
+import base64
+import json
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def b64(s, dtype=np.uint8):
+    return np.frombuffer(base64.b64decode(s), dtype=dtype)
+
+
+def load_golden(name):
+    with open(os.path.join(GOLDEN, name)) as f:
+        return json.load(f)
+
+
+def oracle_decode_sequence(O, cw, ch, pics, refs, qm=None):
+    """pics: list of tensors dicts in coded order, each with keys 'slot', 'ref_fwd', 'ref_bwd'
+    (indices into the `out` dict).  Returns {slot: flat [Y|Cb|Cr] uint8}."""
+    out = dict(refs)
+    for t in pics:
+        out[t["slot"]] = O.decode_picture(
+            t["type"], cw, ch, t["coef_y"], t["coef_cb"], t["coef_cr"], t["qscale"], t["intra"],
+            repadd=t.get("repadd"), mb_dir=t.get("mb_dir"), mv_fwd=t.get("mv_fwd"), mv_bwd=t.get("mv_bwd"),
+            qm=qm, ref_fwd=None if t.get("ref_fwd") is None else out[t["ref_fwd"]],
+            ref_bwd=None if t.get("ref_bwd") is None else out[t["ref_bwd"]])
+    return out
+
+
+def hip_submit(L, dec, t, keep):
+    p = L.make_picture(t["type"], t["slot"], t["coef_y"], t["coef_cb"], t["coef_cr"], t["qscale"], t["intra"],
+                       repadd=t.get("repadd"), mv_fwd=t.get("mv_fwd"), mv_bwd=t.get("mv_bwd"),
+                       mb_dir=t.get("mb_dir"),
+                       ref_fwd_slot=-1 if t.get("ref_fwd") is None else t["ref_fwd"],
+                       ref_bwd_slot=-1 if t.get("ref_bwd") is None else t["ref_bwd"], keep=keep)
+    dec.submit_picture(p)
+
+
+def planes_flat(y, cb, cr):
+    return np.concatenate([y.ravel(), cb.ravel(), cr.ravel()])
