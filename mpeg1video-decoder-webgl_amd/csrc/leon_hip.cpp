@@ -128,8 +128,10 @@ void upload_tables(leon_decoder* d)
 {
     for (int c = 0; c < 8; c++)
         for (int i = 0; i < 8; i++) {
-            d->h_tables.qmT[0][c][i] = d->qm[i * 8 + c];
-            d->h_tables.qmT[1][c][i] = d->qm[64 + i * 8 + c];
+            for (int q = 0; q < 32; q++) {
+                d->h_tables.qO[q][0][c][i] = (uint16_t)(q * d->qm[i * 8 + c]);
+                d->h_tables.qO[q][1][c][i] = (uint16_t)(q * d->qm[64 + i * 8 + c]);
+            }
             d->h_tables.pmT[c][i] = kPremultiplier[i * 8 + c];
         }
 }
@@ -174,8 +176,11 @@ int launch_recon(leon_decoder* d, const PicDesc* d_descs, int n, double bytes, u
 {
     Geom G = d->geom;
     G.n_pics = n;
-    long long waves = (long long)n * G.tasks_per_pic;
-    G.n_wg = (int)((waves + kWavesPerWG - 1) / kWavesPerWG);
+    long long wgs = (long long)n * G.wg_per_pic;
+    // the kernel divides by multiply-high: exact while n_wg * wg_per_pic < 2^32
+    if (wgs > 0x7fffffffLL || wgs * G.wg_per_pic >= (1LL << 32))
+        return fail(LEON_ERR_INVALID, "batch of %d pictures is too large for one launch; split it", n);
+    G.n_wg = (int)wgs;
     TimedLaunch tl{};
     if (d->timing) {
         tl.a = get_event(d);
@@ -266,6 +271,11 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
     G.tasksY = G.gY * (G.ch >> 3);
     G.tasksC = G.gC * (G.ch >> 4);
     G.tasks_per_pic = G.tasksY + 2 * G.tasksC;
+    G.wg_per_pic = (G.tasks_per_pic + kWavesPerWG - 1) / kWavesPerWG;
+    auto inv32 = [](uint32_t dv) { return (uint32_t)(((1ull << 32) + dv - 1) / dv); };   // exact for n*dv < 2^32
+    G.inv_wg_per_pic = G.wg_per_pic == 1 ? 0u : inv32((uint32_t)G.wg_per_pic);
+    G.inv_gY = G.gY == 1 ? 0u : inv32((uint32_t)G.gY);
+    G.inv_gC = G.gC == 1 ? 0u : inv32((uint32_t)G.gC);
     d->plane_bytes = (size_t)G.cw * G.ch * 3 / 2;
     d->slot_stride = (d->plane_bytes + 255) / 256 * 256 + 256;   // tail pad: the 12-byte MC window may over-read 3 bytes
     d->inuse.assign(cfg->n_slots, 0);

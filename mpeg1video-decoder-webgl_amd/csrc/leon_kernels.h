@@ -6,7 +6,7 @@
 //                hand-off) + forward/backward/bidirectional half-pel motion
 //                compensation + residual add + clamp, fused, for a BATCH of
 //                mutually independent pictures.            (K1a+K1b+K2+K2-B)
-//   k_rgba       YCbCr 4:2:0 -> RGBA8, fp64 "CPU twin" or fp32 "GL" flavour. (K3)
+//   k_rgba_*     YCbCr 4:2:0 -> RGBA8, fp64 "CPU twin" or fp32 "GL" flavour. (K3)
 //   k_copy16     streaming 16 B/lane copy = the measured HBM roofline.
 //
 // What the arithmetic follows in /root/reference:
@@ -19,14 +19,18 @@
 // Work decomposition of k_recon: one 64-lane wave = one "block group" = 8
 // horizontally adjacent 8x8 blocks of one plane (64 x 8 samples).  Waves never
 // talk to each other (no __syncthreads); each owns a private LDS strip.
-//   stage 1  lane (r,b): 16-byte load of coefficient row r of block b  -> LDS tile
-//            (8 rows x 128 B: every load instruction covers 8 full 128-B lines)
-//   stage 2  lane (b,c): column c of block b: 8 LDS reads, dequant, butterfly,
-//            floor(v*0.4f), int16 hand-off written transposed to LDS
-//   stage 3  lane (b,n): row n of block b: one 16-byte LDS read, trunc(5w/2),
-//            butterfly, (t+128)/256
-//   stage 4  lane (b,n): 8 predicted samples from the reference plane(s) via
-//            dword loads + v_alignbyte + v_lerp_u8, add, clamp, one 8-byte store
+//   stage 0  every global load of the group is issued up front: the coefficient row
+//            segment (16 B/lane; each load instruction covers 8 full 128-B lines),
+//            the per-macroblock maps, and -- as soon as the vectors are there -- the
+//            reference rows (3 aligned dwords per row), so HBM latency overlaps the IDCT
+//   stage 1  lane (r,b): coefficient row r of block b -> LDS tile [r][b][c]
+//   stage 2  lane (b,c): column c of block b: 8 LDS reads, dequant (rows whose 64
+//            coefficients are all zero are skipped wave-uniformly, exactly like the
+//            shader's `if (X == 0.) continue`), butterfly, floor(v*0.4f), int16
+//            hand-off wrap, trunc(5w/2), written transposed to LDS as int32
+//   stage 3  lane (b,n): row n of block b: two 16-byte LDS reads, butterfly
+//   stage 4  lane (b,n): 8 predicted samples via v_alignbyte + v_lerp_u8, add the
+//            residual, saturate-pack (v_ashr_pk_u8_i32), one 8-byte store
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -54,28 +58,33 @@ struct Geom {
     int32_t gY, gC;              // block groups per block row (luma, chroma)
     int32_t tasksY, tasksC;      // gY*(ch/8), gC*(ch/16)
     int32_t tasks_per_pic;       // tasksY + 2*tasksC
+    int32_t wg_per_pic;          // ceil(tasks_per_pic / 4): a workgroup never straddles pictures
     int32_t n_pics;
-    int32_t n_wg;                // grid size (4 waves per workgroup)
+    int32_t n_wg;                // grid size
+    uint32_t inv_wg_per_pic;     // ceil(2^32 / wg_per_pic)
+    uint32_t inv_gY, inv_gC;     // ceil(2^32 / gY), ceil(2^32 / gC)
     int32_t pad_;
 };
 
-struct Tables {                  // T6, transposed so a lane reads its column as 8 bytes
-    uint8_t qmT[2][8][8];        // [0]=intra [1]=non-intra, [column c][row i]
-    uint8_t pmT[8][8];           // [column c][row i]
+struct Tables {                  // T6, per sequence
+    uint16_t qO[32][2][8][8];    // [quantiser_scale][0 intra | 1 non-intra][column c][row i] = q * Q[i][c]
+    uint8_t pmT[8][8];           // premultiplier, [column c][row i]
 };
 
 static constexpr int kWavesPerWG = 4;
-static constexpr int kLdsCoef = 1024;            // 8 rows x 128 B
-static constexpr int kLdsHandoffPitch = 144;     // 8 rows x 16 B + 16 B skew per block
+static constexpr int kLdsCoef = 1024;            // 8 rows x 128 B of int16
+static constexpr int kLdsHandoffPitch = 288;     // 8 rows x 32 B + 32 B skew per block (bank spread)
 static constexpr int kLdsHandoff = 8 * kLdsHandoffPitch;
 static constexpr int kLdsPerWave = kLdsCoef + kLdsHandoff;
 
-// ---- small integer helpers -------------------------------------------------
+// ---- small helpers -----------------------------------------------------------
 
 // Pointers read out of a PicDesc are generic; telling the compiler they are global
 // turns flat_load/flat_store into global_load/global_store with an SGPR base.
 #define LEON_GLOBAL __attribute__((address_space(1)))
 typedef int v4i __attribute__((ext_vector_type(4)));
+typedef unsigned int v4u __attribute__((ext_vector_type(4)));
+typedef unsigned int v3u __attribute__((ext_vector_type(3)));
 typedef unsigned int v2u __attribute__((ext_vector_type(2)));
 template <typename T>
 __device__ __forceinline__ const LEON_GLOBAL T* gptr(const T* p) { return (const LEON_GLOBAL T*)p; }
@@ -100,7 +109,7 @@ __device__ __forceinline__ uint32_t sat_pk2(int a, int b, uint32_t sh)
     return (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(a, b, sh) & 0xffffu;
 }
 
-// GLSL int '/' 256 (truncation toward zero), 3 VALU ops
+// GLSL int '/' 256 (truncation toward zero)
 __device__ __forceinline__ int div256(int t)
 {
     return (int)(__umul24((unsigned)t >> 31, 255u) + (unsigned)t) >> 8;
@@ -108,7 +117,10 @@ __device__ __forceinline__ int div256(int t)
 
 __device__ __forceinline__ int med3i(int v, int lo, int hi) { return min(max(v, lo), hi); }
 
-// mpeg1video.js:23 / :26.  BIAS is added to X[0] (every output contains +m0 once).
+// n / d by multiply-high with inv = ceil(2^32/d) (0 encodes d == 1); exact for n*d < 2^32
+__device__ __forceinline__ int div_inv(int n, uint32_t inv) { return inv ? (int)__umulhi((uint32_t)n, inv) : n; }
+
+// mpeg1video.js:23 / :26 (same text in both passes)
 __device__ __forceinline__ void butterfly8(const int (&X)[8], int (&o)[8])
 {
     int b1 = X[4];
@@ -140,11 +152,12 @@ __device__ __forceinline__ void butterfly8(const int (&X)[8], int (&o)[8])
     o[7] = y4 - b7;
 }
 
-// COL_INT_3: one coefficient.  qO = quantiser_scale * matrix entry, pm = premultiplier.
-__device__ __forceinline__ int dequant1(int X, int qO, int pm, int nonintra_mask)
+// COL_INT_3: one coefficient.  qO = quantiser_scale * matrix entry, pm = premultiplier,
+// nim = -1 for a non-intra block, 0 for an intra block.
+__device__ __forceinline__ int dequant1(int X, int qO, int pm, int nim)
 {
-    int s = X >> 31;                                  // -1 / 0
-    int x2 = 2 * X + ((s | 1) & nonintra_mask);       // X*2, += sign for non-intra
+    int sgn = med3i(X, -1, 1);
+    int x2 = (X << 1) + (sgn & nim);                 // X*2, += sign(X) for non-intra
     int t = __mul24(x2, qO);                          // |x2| < 2^17, qO < 2^13
     int f = t >> 4;                                   // floor(./16)
     f = (f - (f > 0 ? 1 : 0)) | 1;                    // even -> toward zero; 0 -> +1
@@ -182,6 +195,15 @@ __device__ __forceinline__ uint32_t ref_px_clamped(const LEON_GLOBAL uint8_t* re
     return ref[row_off + (uint32_t)(4 * t + (x & 3))];
 }
 
+// raw reference bytes of one predictor: two rows of 12 bytes starting at the aligned
+// address below the window, plus the byte shift of the window inside them
+struct RefRows {
+    uint32_t l0, l1, l2;        // row y+ay
+    uint32_t m0, m1, m2;        // row y+ay+oddv
+    uint32_t s;                 // window starts at byte s (0..3)
+    uint32_t oh;                // horizontal half-pel flag
+};
+
 // 9 samples px..px+8 of one row, for vectors that leave the picture (rare, divergent)
 __device__ __forceinline__ void gather9_slow(const LEON_GLOBAL uint8_t* ref, uint32_t row_off, int W, int px,
                                              uint32_t& a0, uint32_t& a1, uint32_t& a2)
@@ -197,52 +219,59 @@ __device__ __forceinline__ void gather9_slow(const LEON_GLOBAL uint8_t* ref, uin
     a2 = ref_px_clamped(ref, row_off, W, px + 8);
 }
 
-// 8 predicted samples at (x0..x0+7, y) of one plane for vector (mh, mv) in luma
-// half-pel units.  CHROMA: vector is truncated toward zero first (mv_coef 0.5).
-// `ref` is the plane base (wave-uniform), offsets are 32-bit.
+// Issue the loads for the 8 samples at (x0..x0+7, y) displaced by (mh, mv) [luma
+// half-pel units; CHROMA truncates the vector toward zero first, mv_coef 0.5].
 template <bool CHROMA>
-__device__ __forceinline__ uint2 predict8(const LEON_GLOBAL uint8_t* ref, int W, int H,
-                                          int x0, int y, int mh, int mv)
+__device__ __forceinline__ RefRows fetch_ref(const LEON_GLOBAL uint8_t* ref, int W, int H,
+                                             int x0, int y, int mh, int mv)
 {
     int h = CHROMA ? mh / 2 : mh;
     int v = CHROMA ? mv / 2 : mv;
     int ax = h >> 1, ay = v >> 1;
-    uint32_t oh = h & 1, ov = v & 1;
+    int oh = h & 1, ov = v & 1;
     int px = x0 + ax;
     int py0 = min(max(y + ay, 0), H - 1);
-    int py1 = min(max(y + ay + (int)ov, 0), H - 1);
+    int py1 = min(max(y + ay + ov, 0), H - 1);
     uint32_t r0 = (uint32_t)__mul24(py0, W);
     uint32_t r1 = (uint32_t)__mul24(py1, W);
-    uint32_t a0, a1, a2, c0, c1, c2;
-    if (px >= 0 && px + 7 + (int)oh <= W - 1) {
-        uint32_t s = px & 3;
-        uint32_t xo = (uint32_t)(px & ~3);
-        const LEON_GLOBAL uint32_t* q0 = (const LEON_GLOBAL uint32_t*)(ref + (r0 + xo));
-        const LEON_GLOBAL uint32_t* q1 = (const LEON_GLOBAL uint32_t*)(ref + (r1 + xo));
-        uint32_t l0 = q0[0], l1 = q0[1], l2 = q0[2];
-        uint32_t m0 = q1[0], m1 = q1[1], m2 = q1[2];
-        a0 = __builtin_amdgcn_alignbyte(l1, l0, s);
-        a1 = __builtin_amdgcn_alignbyte(l2, l1, s);
-        a2 = __builtin_amdgcn_alignbyte(0u, l2, s);
-        c0 = __builtin_amdgcn_alignbyte(m1, m0, s);
-        c1 = __builtin_amdgcn_alignbyte(m2, m1, s);
-        c2 = __builtin_amdgcn_alignbyte(0u, m2, s);
+    RefRows R;
+    R.oh = (uint32_t)oh;
+    if (px >= 0 && px + 7 + oh <= W - 1) {
+        R.s = (uint32_t)px & 3u;
+        uint32_t xo = (uint32_t)px & ~3u;
+        v3u a = *(const LEON_GLOBAL v3u*)(ref + (r0 + xo));
+        v3u c = *(const LEON_GLOBAL v3u*)(ref + (r1 + xo));
+        R.l0 = a.x; R.l1 = a.y; R.l2 = a.z;
+        R.m0 = c.x; R.m1 = c.y; R.m2 = c.z;
     } else {                                         // vector leaves the picture (rare)
-        gather9_slow(ref, r0, W, px, a0, a1, a2);
-        gather9_slow(ref, r1, W, px, c0, c1, c2);
+        R.s = 0;
+        gather9_slow(ref, r0, W, px, R.l0, R.l1, R.l2);
+        gather9_slow(ref, r1, W, px, R.m0, R.m1, R.m2);
     }
-    // horizontal neighbour = same bytes shifted by oh (0 or 1)
-    uint32_t b0 = __builtin_amdgcn_alignbyte(a1, a0, oh);
-    uint32_t b1 = __builtin_amdgcn_alignbyte(a2, a1, oh);
-    uint32_t d0 = __builtin_amdgcn_alignbyte(c1, c0, oh);
-    uint32_t d1 = __builtin_amdgcn_alignbyte(c2, c1, oh);
-    uint2 p;
+    return R;
+}
+
+// (a+b+c+d+2)>>2 / (a+b+1)>>1 / a, selected by the half-pel flags through operand
+// duplication: a==b when !oh (shift 0), rows equal when !ov (same row fetched twice)
+__device__ __forceinline__ v2u predict8(const RefRows& R)
+{
+    uint32_t a0 = __builtin_amdgcn_alignbyte(R.l1, R.l0, R.s);
+    uint32_t a1 = __builtin_amdgcn_alignbyte(R.l2, R.l1, R.s);
+    uint32_t a2 = __builtin_amdgcn_alignbyte(0u, R.l2, R.s);
+    uint32_t c0 = __builtin_amdgcn_alignbyte(R.m1, R.m0, R.s);
+    uint32_t c1 = __builtin_amdgcn_alignbyte(R.m2, R.m1, R.s);
+    uint32_t c2 = __builtin_amdgcn_alignbyte(0u, R.m2, R.s);
+    uint32_t b0 = __builtin_amdgcn_alignbyte(a1, a0, R.oh);
+    uint32_t b1 = __builtin_amdgcn_alignbyte(a2, a1, R.oh);
+    uint32_t d0 = __builtin_amdgcn_alignbyte(c1, c0, R.oh);
+    uint32_t d1 = __builtin_amdgcn_alignbyte(c2, c1, R.oh);
+    v2u p;
     p.x = avg4_u8x4(a0, b0, c0, d0);
     p.y = avg4_u8x4(a1, b1, c1, d1);
     return p;
 }
 
-// byte m of `pred` moved to bits 8..15 (so that it adds as pred*256), one v_perm_b32
+// byte M of `pred` moved to bits 8..15 (so that it adds as pred*256), one v_perm_b32
 template <int M>
 __device__ __forceinline__ uint32_t pred_x256(uint32_t pred)
 {
@@ -263,106 +292,120 @@ __device__ __forceinline__ void recon_group(const PicDesc& pd, const Geom& G, co
     const uint32_t plane_off = comp == 0 ? 0u : (comp == 1 ? ysz : ysz + (ysz >> 2));
     const LEON_GLOBAL int16_t* coef = gptr(pd.coef[comp]);
     const LEON_GLOBAL Tables* T = gptr(Tg);
+    const int hi3 = lane >> 3, lo3 = lane & 7;
 
-    // ---- stage 1: coefficient rows -> LDS tile [r][b][c] -----------------------
+    // ---- stage 0: issue the loads ---------------------------------------------------
+    v4i cv = {0, 0, 0, 0};
     {
-        int r = lane >> 3, b = lane & 7;
-        int Q = g * 8 + b;
-        v4i v = {0, 0, 0, 0};
+        int Q = g * 8 + lo3;                          // lane (r = hi3, b = lo3)
         if (Q < bw)
-            v = *(const LEON_GLOBAL v4i*)(coef + ((uint32_t)__mul24(8 * R + r, W) + (uint32_t)(8 * Q)));
-        *reinterpret_cast<v4i*>(lds + r * 128 + b * 16) = v;
+            cv = *(const LEON_GLOBAL v4i*)(coef + ((uint32_t)__mul24(8 * R + hi3, W) + (uint32_t)(8 * Q)));
     }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
-    const int b = lane >> 3;
+    const int b = hi3;                                // from here on: lane (b, c) / (b, n)
     const int Qb = g * 8 + b;
     const bool valid = Qb < bw;
     const int Qs = valid ? Qb : bw - 1;
     const uint32_t mb = (uint32_t)(CHROMA ? R * G.mbw + Qs : (R >> 1) * G.mbw + (Qs >> 1));
+    const int q = gptr(pd.qscale)[mb] & 31;
+    const bool ia = gptr(pd.intra)[mb] != 0;          // I pictures honour the map too (COL_3)
+    const int y = 8 * R + lo3;                        // row of lane (b, n = lo3)
+    const int x0 = 8 * Qs;
+    bool rep = false;
+    int dir = 3;
+    RefRows rf, rb;
+    if (TYPE != 1) {
+        rep = gptr(pd.repadd)[mb] >= 128;             // .r > 0.5
+        const uint32_t mf = *(const LEON_GLOBAL uint32_t*)(gptr(pd.mv_fwd) + 2 * mb);
+        const int fh = (int)(short)(mf & 0xffff), fv = (int)mf >> 16;
+        const LEON_GLOBAL uint8_t* rfw = gptr(pd.ref_fwd) + plane_off;
+        if (TYPE == 2) {
+            rf = fetch_ref<CHROMA>(rfw, W, H, x0, y, fh, fv);
+        } else {
+            const uint32_t mk = *(const LEON_GLOBAL uint32_t*)(gptr(pd.mv_bwd) + 2 * mb);
+            const int bh = (int)(short)(mk & 0xffff), bv = (int)mk >> 16;
+            dir = gptr(pd.mb_dir)[mb] & 3;
+            // a missing direction re-uses the other one: (p + p + 1) >> 1 == p
+            const bool usef = (dir & 1) != 0, useb = (dir & 2) != 0;
+            const LEON_GLOBAL uint8_t* rbw = gptr(pd.ref_bwd) + plane_off;
+            rf = fetch_ref<CHROMA>(usef ? rfw : rbw, W, H, x0, y, usef ? fh : bh, usef ? fv : bv);
+            rb = fetch_ref<CHROMA>(useb ? rbw : rfw, W, H, x0, y, useb ? bh : fh, useb ? bv : fv);
+        }
+    }
+    const int c = lo3;
+    const v4u qo8 = *(const LEON_GLOBAL v4u*)(&T->qO[q][ia ? 0 : 1][c][0]);
+    const v2u pm8 = *(const LEON_GLOBAL v2u*)(&T->pmT[c][0]);
+
+    // ---- stage 1: coefficient rows -> LDS tile [r][b][c] -----------------------
+    *reinterpret_cast<v4i*>(lds + hi3 * 128 + lo3 * 16) = cv;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- stage 2: column pass --------------------------------------------------
     {
-        int c = lane & 7;
-        int q = gptr(pd.qscale)[mb];
-        bool ia = gptr(pd.intra)[mb] != 0;                   // I pictures honour the map too (COL_3)
-        v2u qmc = *(const LEON_GLOBAL v2u*)(&T->qmT[ia ? 0 : 1][c][0]);
-        v2u pmc = *(const LEON_GLOBAL v2u*)(&T->pmT[c][0]);
-        int nim = ia ? 0 : -1;
+        const int nim = ia ? 0 : -1;
         int X[8], v[8];
 #pragma unroll
         for (int i = 0; i < 8; i++)
             X[i] = *reinterpret_cast<const short*>(lds + i * 128 + b * 16 + c * 2);
-        int dc = X[0];
+        const int dc = X[0];
+        const uint32_t qow[4] = {qo8.x, qo8.y, qo8.z, qo8.w};
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            uint32_t Ow = i < 4 ? qmc.x : qmc.y, Pw = i < 4 ? pmc.x : pmc.y;
-            int O = (Ow >> (8 * (i & 3))) & 255;
-            int P = (Pw >> (8 * (i & 3))) & 255;
-            X[i] = dequant1(X[i], __mul24(q, O), P, nim);
+            // all 64 coefficients of this row are zero: nothing to dequantise (wave-uniform)
+            if (__builtin_amdgcn_ballot_w64(X[i] != 0) != 0) {
+                int O = (int)((qow[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+                int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
+                X[i] = dequant1(X[i], O, P, nim);
+            }
         }
         if (c == 0 && ia) X[0] = dc * 256;            // COL_4 / COL_INT_31
         butterfly8(X, v);
-        char* hp = lds + kLdsCoef + b * kLdsHandoffPitch + c * 2;
+        // floor( float(v) * _y ), then int( w / _y ) == trunc(5w/2) == trunc(w * 2.5f)
+        float wf[8];
 #pragma unroll
-        for (int n = 0; n < 8; n++) {
-            int w = (int)floorf((float)v[n] * 0.4f);  // floor( float(v) * _y )
-            *reinterpret_cast<short*>(hp + n * 16) = (short)handoff16(w);
+        for (int n = 0; n < 8; n++) wf[n] = floorf((float)v[n] * 0.4f);
+        float mx = fmaxf(fmaxf(fmaxf(wf[0], wf[1]), fmaxf(wf[2], wf[3])), fmaxf(fmaxf(wf[4], wf[5]), fmaxf(wf[6], wf[7])));
+        float mn = fminf(fminf(fminf(wf[0], wf[1]), fminf(wf[2], wf[3])), fminf(fminf(wf[4], wf[5]), fminf(wf[6], wf[7])));
+        int Xo[8];
+#pragma unroll
+        for (int n = 0; n < 8; n++) Xo[n] = (int)(wf[n] * 2.5f);      // exact product, cvt truncates
+        if (mx > 32767.0f || mn < -32768.0f) {        // outside any real stream: int16 wrap / saturation
+#pragma unroll
+            for (int n = 0; n < 8; n++) {
+                int w = handoff16((int)wf[n]);
+                Xo[n] = (5 * w + (int)((unsigned)w >> 31)) >> 1;
+            }
         }
+        int* hp = reinterpret_cast<int*>(lds + kLdsCoef + b * kLdsHandoffPitch + c * 4);
+#pragma unroll
+        for (int n = 0; n < 8; n++) hp[n * 8] = Xo[n];
     }
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
     // ---- stage 3: row pass -----------------------------------------------------
-    const int n = lane & 7;
     int t[8];
     {
-        int4 wv = *reinterpret_cast<const int4*>(lds + kLdsCoef + b * kLdsHandoffPitch + n * 16);
-        int X[8];
-        const int ww[4] = {wv.x, wv.y, wv.z, wv.w};
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            int w0 = (int)(short)(ww[k] & 0xffff), w1 = ww[k] >> 16;
-            // int( w / 0.4f ) == trunc(5w/2) for every int16 w (tests/test_identities.py)
-            X[2 * k] = (5 * w0 + (int)((unsigned)w0 >> 31)) >> 1;
-            X[2 * k + 1] = (5 * w1 + (int)((unsigned)w1 >> 31)) >> 1;
-        }
-        X[0] += 128;                                  // the "+128" of (t+128)/256
+        const v4i* rp = reinterpret_cast<const v4i*>(lds + kLdsCoef + b * kLdsHandoffPitch + lo3 * 32);
+        v4i w0 = rp[0], w1 = rp[1];
+        int X[8] = {w0.x + 128, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};   // "+128" of (t+128)/256
         butterfly8(X, t);
-        // (t/256 truncating) as an arithmetic shift: add 255 to negative values first
+        // t/256 truncating == arithmetic shift after adding 255 to negative values
 #pragma unroll
         for (int m = 0; m < 8; m++) t[m] += (t[m] >> 31) & 255;
     }
 
     // ---- stage 4: prediction, add, clamp, store ---------------------------------
-    const int y = 8 * R + n;
-    const int x0 = 8 * Qs;
     if (TYPE != 1) {
-        uint2 pred = make_uint2(0u, 0u);
-        const bool rep = gptr(pd.repadd)[mb] >= 128;                  // .r > 0.5
-        const uint32_t mf = *(const LEON_GLOBAL uint32_t*)(gptr(pd.mv_fwd) + 2 * mb);
-        const int fh = (int)(short)(mf & 0xffff), fv = (int)mf >> 16;
-        if (TYPE == 2) {
-            pred = predict8<CHROMA>(gptr(pd.ref_fwd) + plane_off, W, H, x0, y, fh, fv);
-        } else {
-            const uint32_t mbk = *(const LEON_GLOBAL uint32_t*)(gptr(pd.mv_bwd) + 2 * mb);
-            const int bh = (int)(short)(mbk & 0xffff), bv = (int)mbk >> 16;
-            const int dir = gptr(pd.mb_dir)[mb] & 3;
-            // a missing direction re-uses the other one: (p + p + 1) >> 1 == p
-            const bool usef = (dir & 1) != 0;
-            const bool useb = (dir & 2) != 0;
-            const LEON_GLOBAL uint8_t* rfw = gptr(pd.ref_fwd) + plane_off;
-            const LEON_GLOBAL uint8_t* rbw = gptr(pd.ref_bwd) + plane_off;
-            uint2 pf = predict8<CHROMA>(usef ? rfw : rbw, W, H, x0, y, usef ? fh : bh, usef ? fv : bv);
-            uint2 pb = predict8<CHROMA>(useb ? rbw : rfw, W, H, x0, y, useb ? bh : fh, useb ? bv : fv);
-            pred.x = __builtin_amdgcn_lerp(pf.x, pb.x, 0x01010101u);
-            pred.y = __builtin_amdgcn_lerp(pf.y, pb.y, 0x01010101u);
-            if (dir == 0) pred = make_uint2(0u, 0u);
+        v2u pred = predict8(rf);
+        if (TYPE == 3) {
+            v2u pb = predict8(rb);
+            pred.x = __builtin_amdgcn_lerp(pred.x, pb.x, 0x01010101u);
+            pred.y = __builtin_amdgcn_lerp(pred.y, pb.y, 0x01010101u);
         }
-        if (rep) pred = make_uint2(0u, 0u);
+        if (rep || dir == 0) pred = v2u{0u, 0u};
         // clamp(t/256 + pred) == sat_u8((t + pred*256) >> 8)
         t[0] += pred_x256<0>(pred.x);
         t[1] += pred_x256<1>(pred.x);
@@ -395,13 +438,13 @@ __device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G,
                                                int t, char* lds, int lane)
 {
     if (t < G.tasksY) {
-        int R = t / G.gY, g = t - R * G.gY;
+        int R = div_inv(t, G.inv_gY), g = t - R * G.gY;
         recon_group<TYPE, false>(pd, G, T, 0, R, g, lds, lane);
     } else {
         t -= G.tasksY;
         int comp = 1;
         if (t >= G.tasksC) { t -= G.tasksC; comp = 2; }
-        int R = t / G.gC, g = t - R * G.gC;
+        int R = div_inv(t, G.inv_gC), g = t - R * G.gC;
         recon_group<TYPE, true>(pd, G, T, comp, R, g, lds, lane);
     }
 }
@@ -413,10 +456,9 @@ __global__ __launch_bounds__(256) void k_recon(const PicDesc* __restrict__ descs
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int wg = xcd_remap(blockIdx.x, G.n_wg);
-    const int task = wg * kWavesPerWG + wave;
-    const int pic = task / G.tasks_per_pic;
-    if (pic >= G.n_pics) return;
-    const int t = task - pic * G.tasks_per_pic;
+    const int pic = div_inv(wg, G.inv_wg_per_pic);
+    const int t = (wg - pic * G.wg_per_pic) * kWavesPerWG + wave;
+    if (t >= G.tasks_per_pic) return;
     char* lds = smem + wave * kLdsPerWave;
     const PicDesc& pd = descs[pic];
     const int type = pd.type;
