@@ -129,8 +129,8 @@ void upload_tables(leon_decoder* d)
     for (int c = 0; c < 8; c++)
         for (int i = 0; i < 8; i++) {
             for (int q = 0; q < 32; q++) {
-                d->h_tables.qO[q][0][c][i] = (uint16_t)(q * d->qm[i * 8 + c]);
-                d->h_tables.qO[q][1][c][i] = (uint16_t)(q * d->qm[64 + i * 8 + c]);
+                d->h_tables.qO[q][0][c][i] = (uint32_t)(q * d->qm[i * 8 + c]);
+                d->h_tables.qO[q][1][c][i] = (uint32_t)(q * d->qm[64 + i * 8 + c]);
             }
             d->h_tables.pmT[c][i] = kPremultiplier[i * 8 + c];
         }

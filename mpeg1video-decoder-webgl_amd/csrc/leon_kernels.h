@@ -67,7 +67,7 @@ struct Geom {
 };
 
 struct Tables {                  // T6, per sequence
-    uint16_t qO[32][2][8][8];    // [quantiser_scale][0 intra | 1 non-intra][column c][row i] = q * Q[i][c]
+    uint32_t qO[32][2][8][8];    // [quantiser_scale][0 intra | 1 non-intra][column c][row i] = q * Q[i][c]
     uint8_t pmT[8][8];           // premultiplier, [column c][row i]
 };
 
@@ -107,6 +107,34 @@ __device__ __forceinline__ int mad24k(int a, int k, int c)
 __device__ __forceinline__ uint32_t sat_pk2(int a, int b, uint32_t sh)
 {
     return (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(a, b, sh) & 0xffffu;
+}
+
+// typed load at base + 32-bit byte offset: global_load with an SGPR base and a VGPR offset
+template <typename T>
+__device__ __forceinline__ T ldg(const LEON_GLOBAL void* base, uint32_t off)
+{
+    return *(const LEON_GLOBAL T*)((const LEON_GLOBAL char*)base + off);
+}
+
+__device__ __forceinline__ int med3_asm(int v, int lo, int hi)
+{
+    int d;
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(v), "v"(lo), "v"(hi));
+    return d;
+}
+// sign(v) in {-1, 0, 1}
+__device__ __forceinline__ int sign3(int v)
+{
+    int d;
+    asm("v_med3_i32 %0, %1, -1, 1" : "=v"(d) : "v"(v));
+    return d;
+}
+// opaque 24-bit multiply (keeps hipcc from re-deriving 24-bit operand tricks around it)
+__device__ __forceinline__ int mul24_asm(int a, int b)
+{
+    int d;
+    asm("v_mul_i32_i24 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
+    return d;
 }
 
 // GLSL int '/' 256 (truncation toward zero)
@@ -152,18 +180,16 @@ __device__ __forceinline__ void butterfly8(const int (&X)[8], int (&o)[8])
     o[7] = y4 - b7;
 }
 
-// COL_INT_3: one coefficient.  qO = quantiser_scale * matrix entry, pm = premultiplier,
-// nim = -1 for a non-intra block, 0 for an intra block.
-__device__ __forceinline__ int dequant1(int X, int qO, int pm, int nim)
+// COL_INT_3 for one NON-ZERO coefficient.  qO = quantiser_scale * matrix entry,
+// pm = premultiplier, nim = -1 for a non-intra block, 0 for an intra block.
+__device__ __forceinline__ int dequant_nz(int X, int qO, int pm, int nim, int lo2048, int hi2047)
 {
-    int sgn = med3i(X, -1, 1);
-    int x2 = (X << 1) + (sgn & nim);                 // X*2, += sign(X) for non-intra
-    int t = __mul24(x2, qO);                          // |x2| < 2^17, qO < 2^13
+    int x2 = (X << 1) + (sign3(X) & nim);             // X*2, += sign(X) for non-intra
+    int t = mul24_asm(x2, qO);                        // |x2| < 2^17, qO < 2^13
     int f = t >> 4;                                   // floor(./16)
-    f = (f - (f > 0 ? 1 : 0)) | 1;                    // even -> toward zero; 0 -> +1
-    f = med3i(f, -2048, 2047);
-    int r = __mul24(f, pm);
-    return X == 0 ? 0 : r;                            // zeros are skipped
+    f = (f - med3_asm(f, 0, 1)) | 1;                  // even -> toward zero; 0 -> +1
+    f = med3_asm(f, lo2048, hi2047);
+    return __mul24(f, pm);
 }
 
 // _B()/_E() int16 hand-off incl. UNORM8 saturation of the high byte (mpeg1video.js:18)
@@ -306,24 +332,24 @@ __device__ __forceinline__ void recon_group(const PicDesc& pd, const Geom& G, co
     const bool valid = Qb < bw;
     const int Qs = valid ? Qb : bw - 1;
     const uint32_t mb = (uint32_t)(CHROMA ? R * G.mbw + Qs : (R >> 1) * G.mbw + (Qs >> 1));
-    const int q = gptr(pd.qscale)[mb] & 31;
-    const bool ia = gptr(pd.intra)[mb] != 0;          // I pictures honour the map too (COL_3)
+    const int q = ldg<uint8_t>(gptr(pd.qscale), mb) & 31;
+    const bool ia = ldg<uint8_t>(gptr(pd.intra), mb) != 0;   // I pictures honour the map too (COL_3)
     const int y = 8 * R + lo3;                        // row of lane (b, n = lo3)
     const int x0 = 8 * Qs;
     bool rep = false;
     int dir = 3;
     RefRows rf, rb;
     if (TYPE != 1) {
-        rep = gptr(pd.repadd)[mb] >= 128;             // .r > 0.5
-        const uint32_t mf = *(const LEON_GLOBAL uint32_t*)(gptr(pd.mv_fwd) + 2 * mb);
+        rep = ldg<uint8_t>(gptr(pd.repadd), mb) >= 128;      // .r > 0.5
+        const uint32_t mf = ldg<uint32_t>(gptr(pd.mv_fwd), mb * 4);
         const int fh = (int)(short)(mf & 0xffff), fv = (int)mf >> 16;
         const LEON_GLOBAL uint8_t* rfw = gptr(pd.ref_fwd) + plane_off;
         if (TYPE == 2) {
             rf = fetch_ref<CHROMA>(rfw, W, H, x0, y, fh, fv);
         } else {
-            const uint32_t mk = *(const LEON_GLOBAL uint32_t*)(gptr(pd.mv_bwd) + 2 * mb);
+            const uint32_t mk = ldg<uint32_t>(gptr(pd.mv_bwd), mb * 4);
             const int bh = (int)(short)(mk & 0xffff), bv = (int)mk >> 16;
-            dir = gptr(pd.mb_dir)[mb] & 3;
+            dir = ldg<uint8_t>(gptr(pd.mb_dir), mb) & 3;
             // a missing direction re-uses the other one: (p + p + 1) >> 1 == p
             const bool usef = (dir & 1) != 0, useb = (dir & 2) != 0;
             const LEON_GLOBAL uint8_t* rbw = gptr(pd.ref_bwd) + plane_off;
@@ -332,8 +358,9 @@ __device__ __forceinline__ void recon_group(const PicDesc& pd, const Geom& G, co
         }
     }
     const int c = lo3;
-    const v4u qo8 = *(const LEON_GLOBAL v4u*)(&T->qO[q][ia ? 0 : 1][c][0]);
-    const v2u pm8 = *(const LEON_GLOBAL v2u*)(&T->pmT[c][0]);
+    const uint32_t qoff = (uint32_t)q * 512u + (ia ? 0u : 256u) + (uint32_t)c * 32u;
+    const v4u qoA = ldg<v4u>(T, qoff), qoB = ldg<v4u>(T, qoff + 16u);
+    const v2u pm8 = ldg<v2u>(T, (uint32_t)sizeof(T->qO) + (uint32_t)c * 8u);
 
     // ---- stage 1: coefficient rows -> LDS tile [r][b][c] -----------------------
     *reinterpret_cast<v4i*>(lds + hi3 * 128 + lo3 * 16) = cv;
@@ -349,14 +376,15 @@ __device__ __forceinline__ void recon_group(const PicDesc& pd, const Geom& G, co
         for (int i = 0; i < 8; i++)
             X[i] = *reinterpret_cast<const short*>(lds + i * 128 + b * 16 + c * 2);
         const int dc = X[0];
-        const uint32_t qow[4] = {qo8.x, qo8.y, qo8.z, qo8.w};
+        const uint32_t qow[8] = {qoA.x, qoA.y, qoA.z, qoA.w, qoB.x, qoB.y, qoB.z, qoB.w};
+        const int lo2048 = -2048, hi2047 = 2047;
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            // all 64 coefficients of this row are zero: nothing to dequantise (wave-uniform)
-            if (__builtin_amdgcn_ballot_w64(X[i] != 0) != 0) {
-                int O = (int)((qow[i >> 1] >> (16 * (i & 1))) & 0xffffu);
+            // zeros stay zero (the shader's `continue`): lanes with a zero sit the block out,
+            // and a row whose 64 coefficients are all zero costs one compare and a branch
+            if (X[i] != 0) {
                 int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
-                X[i] = dequant1(X[i], O, P, nim);
+                X[i] = dequant_nz(X[i], (int)qow[i], P, nim, lo2048, hi2047);
             }
         }
         if (c == 0 && ia) X[0] = dc * 256;            // COL_4 / COL_INT_31
