@@ -1,0 +1,86 @@
+"""CPU: the synthetic-stream generator and the multi-GPU shard plumbing (gloo, world size 2)."""
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+from helpers import ROOT
+import shards
+import synth as S
+
+
+def test_gop_structures():
+    g = S.gop_ibbp(12)
+    assert [e[0] for e in g] == [1, 3, 3, 2, 3, 3, 2, 3, 3, 2, 3, 3]
+    assert sorted(e[1] for e in g) == list(range(12))
+    lv = S.dependency_levels(g)
+    assert [len(x) for x in lv] == [1, 3, 3, 3, 2]
+    seen = set()
+    for level in lv:                      # every reference is decoded in an earlier level
+        for _, d, f, b in level:
+            assert (f is None or f in seen) and (b is None or b in seen)
+        seen |= {e[1] for e in level}
+    assert [len(x) for x in S.dependency_levels(S.gop_ippp(5))] == [1] * 5
+
+
+def test_pictures_are_decodable_and_in_range():
+    from oracle import oracle_py as O
+    rng = np.random.default_rng(1)
+    cw, ch = 64, 48
+    ref = rng.integers(0, 256, cw * ch * 3 // 2).astype(np.uint8)
+    for ptype in (1, 2, 3):
+        t = S.make_picture(rng, cw, ch, ptype)
+        assert t["coef_y"].shape == (ch, cw) and t["coef_y"].dtype == np.int16
+        assert np.abs(t["coef_y"]).max() <= 255 and t["qscale"].min() >= 1 and t["qscale"].max() <= 31
+        if ptype != 1:
+            mv = t["mv_fwd"].reshape(-1, 2).astype(int)
+            mx = np.tile(np.arange(cw // 16), ch // 16)
+            assert np.all(32 * mx + mv[:, 0] >= 0) and np.all(32 * (mx + 1) + mv[:, 0] <= 2 * cw - 2)
+        out = O.decode_picture(ptype, cw, ch, t["coef_y"], t["coef_cb"], t["coef_cr"], t["qscale"], t["intra"],
+                               repadd=t.get("repadd"), mb_dir=t.get("mb_dir"), mv_fwd=t.get("mv_fwd"),
+                               mv_bwd=t.get("mv_bwd"), ref_fwd=ref, ref_bwd=ref)
+        assert out.shape == (cw * ch * 3 // 2,)
+    # an intra picture of a smooth scene reconstructs close to the scene (sanity of fDCT/quantiser)
+    t = S.make_picture(np.random.default_rng(2), 64, 48, 1)
+    y = O.split_planes(O.decode_picture(1, 64, 48, t["coef_y"], t["coef_cb"], t["coef_cr"], t["qscale"], t["intra"]), 64, 48)[0]
+    assert 30 < y.mean() < 220 and y.std() > 5
+
+
+def test_index_roundtrip_and_sharding():
+    idx = shards.make_index(1920, 1088, 1920, 1080, 3, 19, 12, qm_intra=np.arange(64, dtype=np.uint8))
+    again = shards.parse_index(idx["blob"])
+    assert again["n_gops"] == 19 and again["coded_h"] == 1088 and again["qm_non_intra"] is None
+    assert np.array_equal(again["qm_intra"], np.arange(64)) and np.array_equal(again["key_map"], idx["key_map"])
+    parts = [shards.shard_gops(idx, r, 8) for r in range(8)]
+    assert sorted(sum(parts, [])) == list(range(19)) and max(map(len, parts)) - min(map(len, parts)) <= 1
+
+
+_WORKER = r'''
+import os, sys
+sys.path[:0] = [os.path.join(%(root)r, "mpeg1video-decoder-webgl_amd")]
+import numpy as np, torch, torch.distributed as dist
+import shards
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+idx = shards.make_index(352, 240, 352, 240, 3, 7, 12, qm_intra=np.full(64, 9, np.uint8)) if r == 0 else None
+idx = shards.broadcast_index(idx, dist, torch, src=0)
+mine = shards.shard_gops(idx, r, w)
+assert idx["n_gops"] == 7 and idx["coded_w"] == 352 and int(idx["qm_intra"][5]) == 9
+sums = shards.gather_checksums([1000 * r + g for g in mine][:3], dist, torch)
+assert len(sums) == w and sums[1][0] == 1001
+open(os.path.join(%(out)r, "rank%%d.txt" %% r), "w").write(repr(mine))
+dist.destroy_process_group()
+'''
+
+
+def test_two_rank_gloo_broadcast_of_stream_index(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER % {"root": ROOT, "out": str(tmp_path)})
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", LEON_NO_TORCH="0")
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29731", str(script)],
+                         env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert (tmp_path / "rank0.txt").read_text() == "[0, 2, 4, 6]"
+    assert (tmp_path / "rank1.txt").read_text() == "[1, 3, 5]"
