@@ -20,6 +20,7 @@
 const fs = require('fs');
 const path = require('path');
 const vm = require('vm');
+const crypto = require('crypto');
 
 const REF = process.argv[2] || '/root/reference';
 const OUT = process.argv[3] || path.join(__dirname, '..', 'tests', 'golden');
@@ -188,15 +189,22 @@ function goldenParser(ctx, streamPath) {
   const events = [];
   const pictures = [];
   let cur = null;
-  dec.on('meta', (m) => events.push({ ev: 'meta', w: m.w, h: m.h, d: m.d, a: m.a }));
-  dec.on('seq', (s) => events.push({ ev: 'seq', r: s.r, w: s.w, h: s.h }));
+  dec.on('meta', (e) => { const m = e.detail; events.push({ ev: 'meta', w: m.w, h: m.h, d: m.d, a: m.a }); });
+  dec.on('seq', (e) => { const s = e.detail; events.push({ ev: 'seq', r: s.r, w: s.w, h: s.h }); });
   dec.on('ended', () => events.push({ ev: 'ended' }));
-  dec.on('frame', (f) => {
+  dec.on('frame', (e) => {
+    const f = e.detail;
     f.ybr[0].inuse = 0;                      // stands in for renderFrameGL (player.js:2820)
     // collect the uploads of this picture from the recording
     const pic = { ts: f.ts, type: dec.pictureCodingType, uploads: [] };
     for (const r of rec.splice(0)) {
-      if (r.op === 'tex') pic.uploads.push({ unit: r.unit, w: r.w, h: r.h, fmt: r.fmt, data: b64(r.data) });
+      if (r.op === 'tex') {
+        // big arrays travel as a digest, small ones in full
+        const u = { unit: r.unit, w: r.w, h: r.h, fmt: r.fmt, bytes: r.data.length,
+                    sha256: crypto.createHash('sha256').update(r.data).digest('hex') };
+        if (r.data.length <= 4096) u.data = b64(r.data);
+        pic.uploads.push(u);
+      }
       else if (r.op === 'mv_coef') pic.uploads.push({ mv_coef: r.v });
     }
     pictures.push(pic);

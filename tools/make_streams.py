@@ -1,0 +1,38 @@
+#!/usr/bin/env python3
+"""Generate the synthetic .jsv fixture streams under tests/golden/streams/ (deterministic)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [os.path.join(ROOT, "mpeg1video-decoder-webgl_amd"), os.path.join(ROOT, "tools")]
+import synth as S           # noqa: E402
+import jsv_writer as W      # noqa: E402
+
+
+def build(name, cw, ch, fw, fh, gops, seed, **kw):
+    rng = np.random.default_rng(seed)
+    pics, starts = [], []
+    for gop in gops:
+        starts.append(len(pics))
+        for ptype, disp, f, b in gop:
+            force = 2 if (ptype == S.PIC_B and f is None) else None
+            t = S.make_picture(rng, cw, ch, ptype, force_dir=force, **kw)
+            t["display"] = disp
+            pics.append(t)
+    data, offs = W.write_stream(pics, cw, ch, fw, fh, gop_starts=starts)
+    out = os.path.join(ROOT, "tests", "golden", "streams")
+    os.makedirs(out, exist_ok=True)
+    with open(os.path.join(out, name + ".jsv"), "wb") as f:
+        f.write(data)
+    print(name, len(data), "bytes,", len(pics), "pictures, key map", offs)
+    return pics
+
+
+if __name__ == "__main__":
+    build("tiny_ip_32x32", 32, 32, 32, 32, [S.gop_ippp(3)], 1)
+    # BASELINE config 1 stand-in for the missing videos/leon.jsv: 352x240, 2 GOPs x (I + 11 P), key map
+    build("leon_synth_352x240", 352, 240, 352, 240, [S.gop_ippp(12), S.gop_ippp(12)], 0x4C454F4E)
+    # B pictures (beyond the reference parser, which drops them): product parser only
+    build("ibbp_96x64", 96, 64, 90, 60, [S.gop_ibbp(12), S.gop_ibbp(6)], 7)
