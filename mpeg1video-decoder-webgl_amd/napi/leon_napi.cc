@@ -1,0 +1,326 @@
+// leon_napi.cc -- thin N-API addon: JavaScript (Node) -> the C ABI of include/leon.h.
+// Nothing is computed here; every function forwards to libleon_hip.so and throws a
+// JavaScript Error carrying leon_last_error() on failure (the reference throws from
+// its GL layer the same way: decoders/jsv.js:120-122, :231-233, :1175).
+//
+//   const leon = require('./leon_napi.node');
+//   const h = leon.create({codedWidth, codedHeight, frameWidth, frameHeight, nSlots, deviceId});
+//   h.setQuantMatrices(u8[64], u8[64]); h.acquireSlot(); h.releaseSlot(s); h.freeDecodedSlots();
+//   h.submitPicture({type, outSlot, refFwdSlot, refBwdSlot, coefY, coefCb, coefCr, qscale, intra,
+//                    repadd, mvFwd, mvBwd, mbDir});            // = jsv.prototype.IDCT_GL
+//   h.convertRGBA(slot, flavour) -> Uint8Array; h.readPlanes(slot) -> {y, cb, cr}; h.sync(); h.destroy();
+#include <node_api.h>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include "../../include/leon.h"
+
+namespace {
+
+struct Handle {
+    leon_decoder* d;
+    leon_config cfg;
+};
+
+#define NAPI_OK(call)                                                      \
+    do {                                                                   \
+        if ((call) != napi_ok) {                                           \
+            napi_throw_error(env, nullptr, "N-API call failed: " #call);   \
+            return nullptr;                                                \
+        }                                                                  \
+    } while (0)
+
+napi_value throw_leon(napi_env env, int rc)
+{
+    char msg[600];
+    snprintf(msg, sizeof msg, "leon error %d: %s", rc, leon_last_error());
+    napi_throw_error(env, nullptr, msg);
+    return nullptr;
+}
+
+bool get_i32(napi_env env, napi_value obj, const char* key, int32_t* out, int32_t dflt)
+{
+    napi_value v;
+    bool has = false;
+    *out = dflt;
+    if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return true;
+    if (napi_get_named_property(env, obj, key, &v) != napi_ok) return false;
+    napi_valuetype t;
+    napi_typeof(env, v, &t);
+    if (t == napi_undefined || t == napi_null) return true;
+    return napi_get_value_int32(env, v, out) == napi_ok;
+}
+
+// typed array property -> pointer (nullptr when absent/null); checks the element count
+bool get_array(napi_env env, napi_value obj, const char* key, napi_typedarray_type want, size_t min_len, const void** out)
+{
+    *out = nullptr;
+    napi_value v;
+    bool has = false;
+    if (napi_has_named_property(env, obj, key, &has) != napi_ok || !has) return true;
+    if (napi_get_named_property(env, obj, key, &v) != napi_ok) return false;
+    napi_valuetype t;
+    napi_typeof(env, v, &t);
+    if (t == napi_undefined || t == napi_null) return true;
+    bool is_ta = false;
+    napi_is_typedarray(env, v, &is_ta);
+    if (!is_ta) return false;
+    napi_typedarray_type type;
+    size_t len;
+    void* data;
+    if (napi_get_typedarray_info(env, v, &type, &len, &data, nullptr, nullptr) != napi_ok) return false;
+    if (type != want || len < min_len) return false;
+    *out = data;
+    return true;
+}
+
+Handle* unwrap(napi_env env, napi_callback_info info, size_t* argc, napi_value* argv)
+{
+    napi_value self;
+    if (napi_get_cb_info(env, info, argc, argv, &self, nullptr) != napi_ok) return nullptr;
+    Handle* h = nullptr;
+    if (napi_unwrap(env, self, (void**)&h) != napi_ok || !h || !h->d) {
+        napi_throw_error(env, nullptr, "leon: decoder handle is destroyed or invalid");
+        return nullptr;
+    }
+    return h;
+}
+
+void finalize(napi_env, void* data, void*)
+{
+    Handle* h = (Handle*)data;
+    if (h->d) leon_destroy(h->d);
+    delete h;
+}
+
+napi_value SetQuantMatrices(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2;
+    napi_value argv[2];
+    Handle* h = unwrap(env, info, &argc, argv);
+    if (!h) return nullptr;
+    const uint8_t* m[2] = {nullptr, nullptr};
+    for (size_t i = 0; i < argc && i < 2; i++) {
+        napi_valuetype t;
+        napi_typeof(env, argv[i], &t);
+        if (t == napi_undefined || t == napi_null) continue;
+        napi_typedarray_type type;
+        size_t len;
+        void* data;
+        if (napi_get_typedarray_info(env, argv[i], &type, &len, &data, nullptr, nullptr) != napi_ok || type != napi_uint8_array || len < 64) {
+            napi_throw_type_error(env, nullptr, "setQuantMatrices: Uint8Array(64) expected");
+            return nullptr;
+        }
+        m[i] = (const uint8_t*)data;
+    }
+    int rc = leon_set_quant_matrices(h->d, m[0], m[1]);
+    return rc == LEON_OK ? nullptr : throw_leon(env, rc);
+}
+
+napi_value AcquireSlot(napi_env env, napi_callback_info info)
+{
+    size_t argc = 0;
+    Handle* h = unwrap(env, info, &argc, nullptr);
+    if (!h) return nullptr;
+    int32_t slot = -1;
+    int rc = leon_acquire_slot(h->d, &slot);
+    if (rc != LEON_OK) return throw_leon(env, rc);          // "no free render buffers"
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, slot, &v));
+    return v;
+}
+
+napi_value ReleaseSlot(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    Handle* h = unwrap(env, info, &argc, argv);
+    if (!h) return nullptr;
+    int32_t slot = -1;
+    if (argc < 1 || napi_get_value_int32(env, argv[0], &slot) != napi_ok) {
+        napi_throw_type_error(env, nullptr, "releaseSlot(slot)");
+        return nullptr;
+    }
+    int rc = leon_release_slot(h->d, slot);
+    return rc == LEON_OK ? nullptr : throw_leon(env, rc);
+}
+
+napi_value FreeDecodedSlots(napi_env env, napi_callback_info info)
+{
+    size_t argc = 0;
+    Handle* h = unwrap(env, info, &argc, nullptr);
+    if (!h) return nullptr;
+    int rc = leon_free_decoded_slots(h->d);
+    return rc == LEON_OK ? nullptr : throw_leon(env, rc);
+}
+
+napi_value SubmitPicture(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    Handle* h = unwrap(env, info, &argc, argv);
+    if (!h) return nullptr;
+    if (argc < 1) {
+        napi_throw_type_error(env, nullptr, "submitPicture(picture)");
+        return nullptr;
+    }
+    napi_value p = argv[0];
+    leon_picture pic;
+    memset(&pic, 0, sizeof pic);
+    size_t ny = (size_t)h->cfg.coded_width * h->cfg.coded_height, nc = ny / 4;
+    size_t mbs = (size_t)(h->cfg.coded_width / 16) * (h->cfg.coded_height / 16);
+    bool ok = get_i32(env, p, "type", &pic.type, 0) && get_i32(env, p, "outSlot", &pic.out_slot, -1) &&
+              get_i32(env, p, "refFwdSlot", &pic.ref_fwd_slot, -1) && get_i32(env, p, "refBwdSlot", &pic.ref_bwd_slot, -1) &&
+              get_array(env, p, "coefY", napi_int16_array, ny, (const void**)&pic.coef_y) &&
+              get_array(env, p, "coefCb", napi_int16_array, nc, (const void**)&pic.coef_cb) &&
+              get_array(env, p, "coefCr", napi_int16_array, nc, (const void**)&pic.coef_cr) &&
+              get_array(env, p, "qscale", napi_uint8_array, mbs, (const void**)&pic.qscale) &&
+              get_array(env, p, "intra", napi_uint8_array, mbs, (const void**)&pic.intra) &&
+              get_array(env, p, "repadd", napi_uint8_array, mbs, (const void**)&pic.repadd) &&
+              get_array(env, p, "mvFwd", napi_int16_array, mbs * 2, (const void**)&pic.mv_fwd) &&
+              get_array(env, p, "mvBwd", napi_int16_array, mbs * 2, (const void**)&pic.mv_bwd) &&
+              get_array(env, p, "mbDir", napi_uint8_array, mbs, (const void**)&pic.mb_dir);
+    if (!ok) {
+        napi_throw_type_error(env, nullptr, "submitPicture: a boundary tensor has the wrong type or is too short");
+        return nullptr;
+    }
+    int rc = leon_submit_picture(h->d, &pic);
+    return rc == LEON_OK ? nullptr : throw_leon(env, rc);
+}
+
+napi_value make_u8(napi_env env, size_t bytes, uint8_t** data)
+{
+    napi_value ab, ta;
+    if (napi_create_arraybuffer(env, bytes, (void**)data, &ab) != napi_ok) return nullptr;
+    if (napi_create_typedarray(env, napi_uint8_array, bytes, ab, 0, &ta) != napi_ok) return nullptr;
+    return ta;
+}
+
+napi_value ConvertRGBA(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2;
+    napi_value argv[2];
+    Handle* h = unwrap(env, info, &argc, argv);
+    if (!h) return nullptr;
+    int32_t slot = -1, flavour = 0;
+    if (argc < 1 || napi_get_value_int32(env, argv[0], &slot) != napi_ok) {
+        napi_throw_type_error(env, nullptr, "convertRGBA(slot[, flavour])");
+        return nullptr;
+    }
+    if (argc > 1) napi_get_value_int32(env, argv[1], &flavour);
+    uint8_t* data = nullptr;
+    napi_value ta = make_u8(env, (size_t)h->cfg.frame_width * h->cfg.frame_height * 4, &data);
+    if (!ta) return nullptr;
+    int rc = leon_convert_rgba(h->d, slot, data, LEON_MEM_HOST, flavour);
+    return rc == LEON_OK ? ta : throw_leon(env, rc);
+}
+
+napi_value ReadPlanes(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    Handle* h = unwrap(env, info, &argc, argv);
+    if (!h) return nullptr;
+    int32_t slot = -1;
+    if (argc < 1 || napi_get_value_int32(env, argv[0], &slot) != napi_ok) {
+        napi_throw_type_error(env, nullptr, "readPlanes(slot)");
+        return nullptr;
+    }
+    size_t ny = (size_t)h->cfg.coded_width * h->cfg.coded_height, nc = ny / 4;
+    uint8_t *y, *cb, *cr;
+    napi_value ty = make_u8(env, ny, &y), tcb = make_u8(env, nc, &cb), tcr = make_u8(env, nc, &cr);
+    if (!ty || !tcb || !tcr) return nullptr;
+    int rc = leon_read_planes(h->d, slot, y, cb, cr);
+    if (rc != LEON_OK) return throw_leon(env, rc);
+    napi_value o;
+    NAPI_OK(napi_create_object(env, &o));
+    napi_set_named_property(env, o, "y", ty);
+    napi_set_named_property(env, o, "cb", tcb);
+    napi_set_named_property(env, o, "cr", tcr);
+    return o;
+}
+
+napi_value Sync(napi_env env, napi_callback_info info)
+{
+    size_t argc = 0;
+    Handle* h = unwrap(env, info, &argc, nullptr);
+    if (!h) return nullptr;
+    int rc = leon_sync(h->d);
+    return rc == LEON_OK ? nullptr : throw_leon(env, rc);
+}
+
+napi_value Destroy(napi_env env, napi_callback_info info)
+{
+    size_t argc = 0;
+    napi_value self;
+    napi_get_cb_info(env, info, &argc, nullptr, &self, nullptr);
+    Handle* h = nullptr;
+    if (napi_unwrap(env, self, (void**)&h) == napi_ok && h && h->d) {
+        leon_destroy(h->d);
+        h->d = nullptr;
+    }
+    return nullptr;
+}
+
+napi_value Create(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    if (argc < 1) {
+        napi_throw_type_error(env, nullptr, "create({codedWidth, codedHeight, ...})");
+        return nullptr;
+    }
+    Handle* h = new Handle();
+    memset(&h->cfg, 0, sizeof h->cfg);
+    h->d = nullptr;
+    bool ok = get_i32(env, argv[0], "codedWidth", &h->cfg.coded_width, 0) && get_i32(env, argv[0], "codedHeight", &h->cfg.coded_height, 0) &&
+              get_i32(env, argv[0], "frameWidth", &h->cfg.frame_width, 0) && get_i32(env, argv[0], "frameHeight", &h->cfg.frame_height, 0) &&
+              get_i32(env, argv[0], "nSlots", &h->cfg.n_slots, 13) && get_i32(env, argv[0], "deviceId", &h->cfg.device_id, 0);
+    if (!ok) {
+        delete h;
+        napi_throw_type_error(env, nullptr, "create: integer fields expected");
+        return nullptr;
+    }
+    if (!h->cfg.frame_width) h->cfg.frame_width = h->cfg.coded_width;
+    if (!h->cfg.frame_height) h->cfg.frame_height = h->cfg.coded_height;
+    int rc = leon_create(&h->cfg, &h->d);
+    if (rc != LEON_OK) {
+        delete h;
+        return throw_leon(env, rc);
+    }
+    napi_value obj;
+    NAPI_OK(napi_create_object(env, &obj));
+    NAPI_OK(napi_wrap(env, obj, h, finalize, nullptr, nullptr));
+    const struct { const char* name; napi_callback fn; } methods[] = {
+        {"setQuantMatrices", SetQuantMatrices}, {"acquireSlot", AcquireSlot}, {"releaseSlot", ReleaseSlot},
+        {"freeDecodedSlots", FreeDecodedSlots}, {"submitPicture", SubmitPicture}, {"convertRGBA", ConvertRGBA},
+        {"readPlanes", ReadPlanes}, {"sync", Sync}, {"destroy", Destroy}};
+    for (auto& m : methods) {
+        napi_value fn;
+        NAPI_OK(napi_create_function(env, m.name, NAPI_AUTO_LENGTH, m.fn, nullptr, &fn));
+        NAPI_OK(napi_set_named_property(env, obj, m.name, fn));
+    }
+    return obj;
+}
+
+napi_value AbiVersion(napi_env env, napi_callback_info)
+{
+    napi_value v;
+    NAPI_OK(napi_create_int32(env, leon_abi_version(), &v));
+    return v;
+}
+
+napi_value Init(napi_env env, napi_value exports)
+{
+    napi_value fn;
+    NAPI_OK(napi_create_function(env, "create", NAPI_AUTO_LENGTH, Create, nullptr, &fn));
+    NAPI_OK(napi_set_named_property(env, exports, "create", fn));
+    NAPI_OK(napi_create_function(env, "abiVersion", NAPI_AUTO_LENGTH, AbiVersion, nullptr, &fn));
+    NAPI_OK(napi_set_named_property(env, exports, "abiVersion", fn));
+    return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)
