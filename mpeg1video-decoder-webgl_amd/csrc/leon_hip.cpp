@@ -544,7 +544,10 @@ int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, vo
             size_t nd = (size_t)G.fw * G.fh * n;
             hipLaunchKernelGGL(k_fill255, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, d->stream, (uint32_t*)rgba_device, nd);
         }
-        if (G.cols > 0 && G.rows > 0)
+        if (G.cols > 0 && G.rows > 0 && (G.fw & 7) == 0 && ((size_t)rgba_device & 15) == 0)
+            hipLaunchKernelGGL(k_rgba_twin8, dim3((G.fw / 8 + 63) / 64, G.rows, n), dim3(64), 0, d->stream,
+                               d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
+        else if (G.cols > 0 && G.rows > 0)
             hipLaunchKernelGGL(k_rgba_twin, dim3((G.cols + 255) / 256, G.rows, n), dim3(256), 0, d->stream,
                                d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
     } else {
@@ -670,7 +673,7 @@ int leon_measure_copy_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, do
     hipEventCreate(&a);
     hipEventCreate(&b);
     size_t n = bytes / 16;
-    int grid = 256 * 8;
+    unsigned grid = (unsigned)((n + 255) / 256);
     hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, d->stream, src, dst, n);   // warm-up
     hipEventRecord(a, d->stream);
     for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, d->stream, src, dst, n);

@@ -552,6 +552,50 @@ __global__ __launch_bounds__(256) void k_rgba_twin(const uint8_t* __restrict__ s
     *reinterpret_cast<uint32_t*>(dst + d2 + 4) = px[3];
 }
 
+// Fast path of the CPU twin for frame widths that are a multiple of 8 (no index drift, whole
+// 16-byte stores): one thread = 8 x 2 pixels = four 2x2 quads; same fp64 operations in the same
+// order as k_rgba_twin.
+__global__ __launch_bounds__(256) void k_rgba_twin8(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
+                                                    uint8_t* __restrict__ rgba, RgbaGeom G)
+{
+    const int col8 = blockIdx.x * blockDim.x + threadIdx.x;     // group of 8 columns
+    const int row = blockIdx.y;                                 // row pair
+    const int f = blockIdx.z;
+    if (col8 * 8 >= G.fw) return;
+    const size_t stride = ((size_t)G.slot_stride_hi << 32) | G.slot_stride_lo;
+    const uint8_t* Y = slots + (size_t)slot_ids[f] * stride;
+    const uint8_t* Cb = Y + (size_t)G.cw * G.ch;
+    const uint8_t* Cr = Cb + ((size_t)G.cw * G.ch >> 2);
+    const int hw = G.cw >> 1;
+    const uint2 y0 = *reinterpret_cast<const uint2*>(Y + (size_t)(2 * row) * G.cw + 8 * col8);
+    const uint2 y1 = *reinterpret_cast<const uint2*>(Y + (size_t)(2 * row + 1) * G.cw + 8 * col8);
+    const uint32_t cb4 = *reinterpret_cast<const uint32_t*>(Cb + (size_t)row * hw + 4 * col8);
+    const uint32_t cr4 = *reinterpret_cast<const uint32_t*>(Cr + (size_t)row * hw + 4 * col8);
+    uint32_t o0[8], o1[8];
+    const uint32_t yy0[2] = {y0.x, y0.y}, yy1[2] = {y1.x, y1.y};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        const double yuvr = (double)((cr4 >> (8 * q)) & 255u) - 128.0, yuvb = (double)((cb4 >> (8 * q)) & 255u) - 128.0;
+        const double r = yuvr * 1.59603;
+        const double g = (-0.81297 * yuvr) - (0.39176 * yuvb);
+        const double b = yuvb * 2.01723;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int px = 2 * q + k;
+            const double ya = ((double)((yy0[px >> 2] >> (8 * (px & 3))) & 255u) - 16.0) * 1.16438;
+            const double yb = ((double)((yy1[px >> 2] >> (8 * (px & 3))) & 255u) - 16.0) * 1.16438;
+            o0[px] = u8_clamped(r + ya) | (u8_clamped(g + ya) << 8) | (u8_clamped(b + ya) << 16) | 0xff000000u;
+            o1[px] = u8_clamped(r + yb) | (u8_clamped(g + yb) << 8) | (u8_clamped(b + yb) << 16) | 0xff000000u;
+        }
+    }
+    uint8_t* d0 = rgba + ((size_t)f * G.fw * G.fh + (size_t)(2 * row) * G.fw + 8 * col8) * 4;
+    uint8_t* d1 = d0 + (size_t)G.fw * 4;
+    reinterpret_cast<uint4*>(d0)[0] = make_uint4(o0[0], o0[1], o0[2], o0[3]);
+    reinterpret_cast<uint4*>(d0)[1] = make_uint4(o0[4], o0[5], o0[6], o0[7]);
+    reinterpret_cast<uint4*>(d1)[0] = make_uint4(o1[0], o1[1], o1[2], o1[3]);
+    reinterpret_cast<uint4*>(d1)[1] = make_uint4(o1[4], o1[5], o1[6], o1[7]);
+}
+
 // fills what the quad loop never writes (odd last row / column, drift leftovers) with 255
 __global__ __launch_bounds__(256) void k_fill255(uint32_t* __restrict__ p, size_t n_dwords)
 {
@@ -592,11 +636,12 @@ __global__ __launch_bounds__(256) void k_rgba_gl(const uint8_t* __restrict__ slo
 }
 
 // ---- measured HBM roofline -----------------------------------------------------------
+// One 16-byte element per thread, no loop: the fastest of the copy shapes probed on MI355X
+// (tools/probe/bw_probe.cpp: 6.3 TB/s vs 4.8-5.9 TB/s for grid-stride forms).
 __global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    const size_t step = (size_t)gridDim.x * blockDim.x;
-    for (; i < n; i += step) dst[i] = src[i];
+    if (i < n) dst[i] = src[i];
 }
 
 }  // namespace leon
