@@ -268,9 +268,9 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
     G.mbh = G.ch >> 4;
     G.gY = ((G.cw >> 3) + 7) >> 3;
     G.gC = ((G.cw >> 4) + 7) >> 3;
-    G.tasksY = G.gY * (G.ch >> 3);
-    G.tasksC = G.gC * (G.ch >> 4);
-    G.tasks_per_pic = G.tasksY + 2 * G.tasksC;
+    G.tasksY = G.gY * G.mbh;            // one task = both block rows of a macroblock row
+    G.tasksC = G.gC * G.mbh;            // one task = the Cb and the Cr group of a block row
+    G.tasks_per_pic = G.tasksY + G.tasksC;
     G.wg_per_pic = (G.tasks_per_pic + kWavesPerWG - 1) / kWavesPerWG;
     auto inv32 = [](uint32_t dv) { return (uint32_t)(((1ull << 32) + dv - 1) / dv); };   // exact for n*dv < 2^32
     G.inv_wg_per_pic = G.wg_per_pic == 1 ? 0u : inv32((uint32_t)G.wg_per_pic);

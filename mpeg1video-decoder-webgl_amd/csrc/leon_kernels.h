@@ -56,8 +56,8 @@ struct Geom {
     int32_t cw, ch;              // coded luma size
     int32_t mbw, mbh;
     int32_t gY, gC;              // block groups per block row (luma, chroma)
-    int32_t tasksY, tasksC;      // gY*(ch/8), gC*(ch/16)
-    int32_t tasks_per_pic;       // tasksY + 2*tasksC
+    int32_t tasksY, tasksC;      // gY*mbh luma tasks (two block rows each), gC*mbh chroma tasks (Cb + Cr)
+    int32_t tasks_per_pic;       // tasksY + tasksC
     int32_t wg_per_pic;          // ceil(tasks_per_pic / 4): a workgroup never straddles pictures
     int32_t n_pics;
     int32_t n_wg;                // grid size
@@ -245,24 +245,18 @@ __device__ __forceinline__ void gather9_slow(const LEON_GLOBAL uint8_t* ref, uin
     a2 = ref_px_clamped(ref, row_off, W, px + 8);
 }
 
-// Issue the loads for the 8 samples at (x0..x0+7, y) displaced by (mh, mv) [luma
-// half-pel units; CHROMA truncates the vector toward zero first, mv_coef 0.5].
-template <bool CHROMA>
-__device__ __forceinline__ RefRows fetch_ref(const LEON_GLOBAL uint8_t* ref, int W, int H,
-                                             int x0, int y, int mh, int mv)
+// Issue the loads of one predictor: rows y+ay and y+ay+ov, window columns px..px+8.
+// px / oh / ov / in_pic come from the task prologue (shared by both halves).
+__device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, int W, int H, int y,
+                                              int px, int ay, int oh, int ov, bool in_pic)
 {
-    int h = CHROMA ? mh / 2 : mh;
-    int v = CHROMA ? mv / 2 : mv;
-    int ax = h >> 1, ay = v >> 1;
-    int oh = h & 1, ov = v & 1;
-    int px = x0 + ax;
     int py0 = min(max(y + ay, 0), H - 1);
     int py1 = min(max(y + ay + ov, 0), H - 1);
     uint32_t r0 = (uint32_t)__mul24(py0, W);
     uint32_t r1 = (uint32_t)__mul24(py1, W);
     RefRows R;
     R.oh = (uint32_t)oh;
-    if (px >= 0 && px + 7 + oh <= W - 1) {
+    if (in_pic) {
         R.s = (uint32_t)px & 3u;
         uint32_t xo = (uint32_t)px & ~3u;
         v3u a = *(const LEON_GLOBAL v3u*)(ref + (r0 + xo));
@@ -305,150 +299,191 @@ __device__ __forceinline__ uint32_t pred_x256(uint32_t pred)
     return __builtin_amdgcn_perm(0u, pred, 0x0c0c000cu | ((uint32_t)M << 8));
 }
 
-// ---- one block group ------------------------------------------------------------
+// ---- one task = two block groups that share their macroblocks ------------------------
+//   luma  : the upper and lower 64x8 halves of four macroblocks (block rows 2*Rt, 2*Rt+1)
+//   chroma: the Cb and the Cr group at block row Rt
+// Everything that depends only on the macroblock -- maps, vectors and their half-pel
+// decomposition, quantiser tables, the in-picture test -- is computed once per task.
 
 template <int TYPE, bool CHROMA>
-__device__ __forceinline__ void recon_group(const PicDesc& pd, const Geom& G, const Tables* __restrict__ Tg,
-                                            int comp, int R, int g, char* lds, int lane)
+__device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, const Tables* __restrict__ Tg,
+                                           int Rt, int g, char* lds, int lane)
 {
     const int W = CHROMA ? G.cw >> 1 : G.cw;
     const int H = CHROMA ? G.ch >> 1 : G.ch;
     const int bw = W >> 3;
     const uint32_t ysz = (uint32_t)G.cw * (uint32_t)G.ch;
-    const uint32_t plane_off = comp == 0 ? 0u : (comp == 1 ? ysz : ysz + (ysz >> 2));
-    const LEON_GLOBAL int16_t* coef = gptr(pd.coef[comp]);
     const LEON_GLOBAL Tables* T = gptr(Tg);
     const int hi3 = lane >> 3, lo3 = lane & 7;
 
-    // ---- stage 0: issue the loads ---------------------------------------------------
-    v4i cv = {0, 0, 0, 0};
-    {
-        int Q = g * 8 + lo3;                          // lane (r = hi3, b = lo3)
-        if (Q < bw)
-            cv = *(const LEON_GLOBAL v4i*)(coef + ((uint32_t)__mul24(8 * R + hi3, W) + (uint32_t)(8 * Q)));
-    }
-    const int b = hi3;                                // from here on: lane (b, c) / (b, n)
+    // ---- shared prologue ----------------------------------------------------------------
+    const int Qld = g * 8 + lo3;                      // stage-1 role: lane (r = hi3, b = lo3)
+    const bool ld_ok = Qld < bw;
+    const int b = hi3;                                // afterwards: lane (b, c = lo3) / (b, n = lo3)
     const int Qb = g * 8 + b;
     const bool valid = Qb < bw;
     const int Qs = valid ? Qb : bw - 1;
-    const uint32_t mb = (uint32_t)(CHROMA ? R * G.mbw + Qs : (R >> 1) * G.mbw + (Qs >> 1));
+    const uint32_t mb = (uint32_t)(CHROMA ? Rt * G.mbw + Qs : Rt * G.mbw + (Qs >> 1));
     const int q = ldg<uint8_t>(gptr(pd.qscale), mb) & 31;
     const bool ia = ldg<uint8_t>(gptr(pd.intra), mb) != 0;   // I pictures honour the map too (COL_3)
-    const int y = 8 * R + lo3;                        // row of lane (b, n = lo3)
     const int x0 = 8 * Qs;
-    bool rep = false;
-    int dir = 3;
-    RefRows rf, rb;
+    const int c = lo3;
+    bool nopred = false;
+    // per reference: window column, half-pel flags, vertical offset, base selection
+    int pxA = 0, ayA = 0, ohA = 0, ovA = 0, pxB = 0, ayB = 0, ohB = 0, ovB = 0;
+    bool inA = true, inB = true, baseA_fwd = true, baseB_fwd = false;
     if (TYPE != 1) {
-        rep = ldg<uint8_t>(gptr(pd.repadd), mb) >= 128;      // .r > 0.5
+        nopred = ldg<uint8_t>(gptr(pd.repadd), mb) >= 128;    // .r > 0.5
         const uint32_t mf = ldg<uint32_t>(gptr(pd.mv_fwd), mb * 4);
-        const int fh = (int)(short)(mf & 0xffff), fv = (int)mf >> 16;
-        const LEON_GLOBAL uint8_t* rfw = gptr(pd.ref_fwd) + plane_off;
-        if (TYPE == 2) {
-            rf = fetch_ref<CHROMA>(rfw, W, H, x0, y, fh, fv);
-        } else {
+        int fh = (int)(short)(mf & 0xffff), fv = (int)mf >> 16;
+        int bh = 0, bv = 0;
+        if (TYPE == 3) {
             const uint32_t mk = ldg<uint32_t>(gptr(pd.mv_bwd), mb * 4);
-            const int bh = (int)(short)(mk & 0xffff), bv = (int)mk >> 16;
-            dir = ldg<uint8_t>(gptr(pd.mb_dir), mb) & 3;
+            bh = (int)(short)(mk & 0xffff);
+            bv = (int)mk >> 16;
+            const int dir = ldg<uint8_t>(gptr(pd.mb_dir), mb) & 3;
             // a missing direction re-uses the other one: (p + p + 1) >> 1 == p
             const bool usef = (dir & 1) != 0, useb = (dir & 2) != 0;
-            const LEON_GLOBAL uint8_t* rbw = gptr(pd.ref_bwd) + plane_off;
-            rf = fetch_ref<CHROMA>(usef ? rfw : rbw, W, H, x0, y, usef ? fh : bh, usef ? fv : bv);
-            rb = fetch_ref<CHROMA>(useb ? rbw : rfw, W, H, x0, y, useb ? bh : fh, useb ? bv : fv);
+            nopred = nopred || dir == 0;
+            baseA_fwd = usef;
+            baseB_fwd = !useb;
+            int ah = usef ? fh : bh, av = usef ? fv : bv;
+            int ch2 = useb ? bh : fh, cv2 = useb ? bv : fv;
+            fh = ah; fv = av; bh = ch2; bv = cv2;
+        }
+        {   // chroma: vector truncated toward zero first (mv_coef 0.5), then floor / parity
+            int h = CHROMA ? fh / 2 : fh, v = CHROMA ? fv / 2 : fv;
+            pxA = x0 + (h >> 1); ohA = h & 1; ayA = v >> 1; ovA = v & 1;
+            inA = pxA >= 0 && pxA + 7 + ohA <= W - 1;
+        }
+        if (TYPE == 3) {
+            int h = CHROMA ? bh / 2 : bh, v = CHROMA ? bv / 2 : bv;
+            pxB = x0 + (h >> 1); ohB = h & 1; ayB = v >> 1; ovB = v & 1;
+            inB = pxB >= 0 && pxB + 7 + ohB <= W - 1;
         }
     }
-    const int c = lo3;
     const uint32_t qoff = (uint32_t)q * 512u + (ia ? 0u : 256u) + (uint32_t)c * 32u;
     const v4u qoA = ldg<v4u>(T, qoff), qoB = ldg<v4u>(T, qoff + 16u);
     const v2u pm8 = ldg<v2u>(T, (uint32_t)sizeof(T->qO) + (uint32_t)c * 8u);
+    const uint32_t qow[8] = {qoA.x, qoA.y, qoA.z, qoA.w, qoB.x, qoB.y, qoB.z, qoB.w};
+    const int nim = ia ? 0 : -1;
+    const bool dc_lane = c == 0 && ia;
+    char* const lds_wr = lds + hi3 * 128 + lo3 * 16;
+    const char* const lds_col = lds + b * 16 + c * 2;
+    int* const hp = reinterpret_cast<int*>(lds + kLdsCoef + b * kLdsHandoffPitch + c * 4);
+    const v4i* const rp = reinterpret_cast<const v4i*>(lds + kLdsCoef + b * kLdsHandoffPitch + lo3 * 32);
 
-    // ---- stage 1: coefficient rows -> LDS tile [r][b][c] -----------------------
-    *reinterpret_cast<v4i*>(lds + hi3 * 128 + lo3 * 16) = cv;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll 1
+    for (int half = 0; half < 2; half++) {
+        const int comp = CHROMA ? 1 + half : 0;
+        const int R = CHROMA ? Rt : 2 * Rt + half;
+        const uint32_t plane_off = CHROMA ? (half == 0 ? ysz : ysz + (ysz >> 2)) : 0u;
+        const LEON_GLOBAL int16_t* coef = gptr(pd.coef[comp]);
+        const int y = 8 * R + lo3;
 
-    // ---- stage 2: column pass --------------------------------------------------
-    {
-        const int nim = ia ? 0 : -1;
-        int X[8], v[8];
+        // ---- stage 0: issue this half's loads ---------------------------------------------
+        v4i cv = {0, 0, 0, 0};
+        if (ld_ok)
+            cv = *(const LEON_GLOBAL v4i*)(coef + ((uint32_t)__mul24(8 * R + hi3, W) + (uint32_t)(8 * Qld)));
+        RefRows rf, rb;
+        if (TYPE != 1) {
+            const LEON_GLOBAL uint8_t* rfw = gptr(pd.ref_fwd) + plane_off;
+            const LEON_GLOBAL uint8_t* rbw = TYPE == 3 ? gptr(pd.ref_bwd) + plane_off : rfw;
+            rf = fetch_rows(TYPE == 3 ? (baseA_fwd ? rfw : rbw) : rfw, W, H, y, pxA, ayA, ohA, ovA, inA);
+            if (TYPE == 3) rb = fetch_rows(baseB_fwd ? rfw : rbw, W, H, y, pxB, ayB, ohB, ovB, inB);
+        }
+
+        // ---- stage 1: coefficient rows -> LDS tile [r][b][c] ------------------------------
+        *reinterpret_cast<v4i*>(lds_wr) = cv;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+        int t[8];
+        int X[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++)
-            X[i] = *reinterpret_cast<const short*>(lds + i * 128 + b * 16 + c * 2);
-        const int dc = X[0];
-        const uint32_t qow[8] = {qoA.x, qoA.y, qoA.z, qoA.w, qoB.x, qoB.y, qoB.z, qoB.w};
-        const int lo2048 = -2048, hi2047 = 2047;
+        for (int i = 0; i < 8; i++) X[i] = *reinterpret_cast<const short*>(lds_col + i * 128);
+        const int any = (X[0] | X[1] | X[2]) | (X[3] | X[4] | X[5]) | (X[6] | X[7]);
+        if (__builtin_amdgcn_ballot_w64(any != 0) == 0) {
+            // no coefficient in any of the 8 blocks: residual 0 = (0 + 128) / 256
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            // zeros stay zero (the shader's `continue`): lanes with a zero sit the block out,
-            // and a row whose 64 coefficients are all zero costs one compare and a branch
-            if (X[i] != 0) {
-                int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
-                X[i] = dequant_nz(X[i], (int)qow[i], P, nim, lo2048, hi2047);
+            for (int m = 0; m < 8; m++) t[m] = 128;
+        } else {
+            // ---- stage 2: column pass ------------------------------------------------------
+            const int dc = X[0];
+            const int lo2048 = -2048, hi2047 = 2047;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                // zeros stay zero (the shader's `continue`): lanes with a zero sit the block out,
+                // and a row whose 64 coefficients are all zero costs one compare and a branch
+                if (X[i] != 0) {
+                    int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
+                    X[i] = dequant_nz(X[i], (int)qow[i], P, nim, lo2048, hi2047);
+                }
             }
-        }
-        if (c == 0 && ia) X[0] = dc * 256;            // COL_4 / COL_INT_31
-        butterfly8(X, v);
-        // floor( float(v) * _y ), then int( w / _y ) == trunc(5w/2) == trunc(w * 2.5f)
-        float wf[8];
+            if (dc_lane) X[0] = dc * 256;                 // COL_4 / COL_INT_31
+            int v[8];
+            butterfly8(X, v);
+            // floor( float(v) * _y ), then int( w / _y ) == trunc(5w/2) == trunc(w * 2.5f)
+            float wf[8];
 #pragma unroll
-        for (int n = 0; n < 8; n++) wf[n] = floorf((float)v[n] * 0.4f);
-        float mx = fmaxf(fmaxf(fmaxf(wf[0], wf[1]), fmaxf(wf[2], wf[3])), fmaxf(fmaxf(wf[4], wf[5]), fmaxf(wf[6], wf[7])));
-        float mn = fminf(fminf(fminf(wf[0], wf[1]), fminf(wf[2], wf[3])), fminf(fminf(wf[4], wf[5]), fminf(wf[6], wf[7])));
-        int Xo[8];
+            for (int n = 0; n < 8; n++) wf[n] = floorf((float)v[n] * 0.4f);
+            const float mx = fmaxf(fmaxf(fmaxf(fabsf(wf[0]), fabsf(wf[1])), fmaxf(fabsf(wf[2]), fabsf(wf[3]))),
+                                   fmaxf(fmaxf(fabsf(wf[4]), fabsf(wf[5])), fmaxf(fabsf(wf[6]), fabsf(wf[7]))));
+            int Xo[8];
 #pragma unroll
-        for (int n = 0; n < 8; n++) Xo[n] = (int)(wf[n] * 2.5f);      // exact product, cvt truncates
-        if (mx > 32767.0f || mn < -32768.0f) {        // outside any real stream: int16 wrap / saturation
+            for (int n = 0; n < 8; n++) Xo[n] = (int)(wf[n] * 2.5f);   // exact product, cvt truncates
+            if (mx > 32767.0f) {                          // outside any real stream: int16 wrap / saturation
 #pragma unroll
-            for (int n = 0; n < 8; n++) {
-                int w = handoff16((int)wf[n]);
-                Xo[n] = (5 * w + (int)((unsigned)w >> 31)) >> 1;
+                for (int n = 0; n < 8; n++) {
+                    int w = handoff16((int)wf[n]);
+                    Xo[n] = (5 * w + (int)((unsigned)w >> 31)) >> 1;
+                }
             }
-        }
-        int* hp = reinterpret_cast<int*>(lds + kLdsCoef + b * kLdsHandoffPitch + c * 4);
 #pragma unroll
-        for (int n = 0; n < 8; n++) hp[n * 8] = Xo[n];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            for (int n = 0; n < 8; n++) hp[n * 8] = Xo[n];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- stage 3: row pass -----------------------------------------------------
-    int t[8];
-    {
-        const v4i* rp = reinterpret_cast<const v4i*>(lds + kLdsCoef + b * kLdsHandoffPitch + lo3 * 32);
-        v4i w0 = rp[0], w1 = rp[1];
-        int X[8] = {w0.x + 128, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};   // "+128" of (t+128)/256
-        butterfly8(X, t);
-        // t/256 truncating == arithmetic shift after adding 255 to negative values
+            // ---- stage 3: row pass ---------------------------------------------------------
+            v4i w0 = rp[0], w1 = rp[1];
+            int Y[8] = {w0.x + 128, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};   // "+128" of (t+128)/256
+            butterfly8(Y, t);
+            // t/256 truncating == arithmetic shift after adding 255 to negative values
 #pragma unroll
-        for (int m = 0; m < 8; m++) t[m] += (t[m] >> 31) & 255;
-    }
-
-    // ---- stage 4: prediction, add, clamp, store ---------------------------------
-    if (TYPE != 1) {
-        v2u pred = predict8(rf);
-        if (TYPE == 3) {
-            v2u pb = predict8(rb);
-            pred.x = __builtin_amdgcn_lerp(pred.x, pb.x, 0x01010101u);
-            pred.y = __builtin_amdgcn_lerp(pred.y, pb.y, 0x01010101u);
+            for (int m = 0; m < 8; m++) t[m] += (t[m] >> 31) & 255;
         }
-        if (rep || dir == 0) pred = v2u{0u, 0u};
-        // clamp(t/256 + pred) == sat_u8((t + pred*256) >> 8)
-        t[0] += pred_x256<0>(pred.x);
-        t[1] += pred_x256<1>(pred.x);
-        t[2] += pred_x256<2>(pred.x);
-        t[3] += pred_x256<3>(pred.x);
-        t[4] += pred_x256<0>(pred.y);
-        t[5] += pred_x256<1>(pred.y);
-        t[6] += pred_x256<2>(pred.y);
-        t[7] += pred_x256<3>(pred.y);
+
+        // ---- stage 4: prediction, add, clamp, store ------------------------------------------
+        if (TYPE != 1) {
+            v2u pred = predict8(rf);
+            if (TYPE == 3) {
+                v2u pb = predict8(rb);
+                pred.x = __builtin_amdgcn_lerp(pred.x, pb.x, 0x01010101u);
+                pred.y = __builtin_amdgcn_lerp(pred.y, pb.y, 0x01010101u);
+            }
+            if (nopred) pred = v2u{0u, 0u};
+            // clamp(t/256 + pred) == sat_u8((t + pred*256) >> 8)
+            t[0] += pred_x256<0>(pred.x);
+            t[1] += pred_x256<1>(pred.x);
+            t[2] += pred_x256<2>(pred.x);
+            t[3] += pred_x256<3>(pred.x);
+            t[4] += pred_x256<0>(pred.y);
+            t[5] += pred_x256<1>(pred.y);
+            t[6] += pred_x256<2>(pred.y);
+            t[7] += pred_x256<3>(pred.y);
+        }
+        v2u o;
+        o.x = sat_pk2(t[0], t[1], 8) | (sat_pk2(t[2], t[3], 8) << 16);
+        o.y = sat_pk2(t[4], t[5], 8) | (sat_pk2(t[6], t[7], 8) << 16);
+        if (valid)
+            *(LEON_GLOBAL v2u*)(gptr_mut(pd.out) + (plane_off + (uint32_t)__mul24(y, W) + (uint32_t)x0)) = o;
+        // the next half overwrites the LDS strip: order its writes behind this half's reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    v2u o;
-    o.x = sat_pk2(t[0], t[1], 8) | (sat_pk2(t[2], t[3], 8) << 16);
-    o.y = sat_pk2(t[4], t[5], 8) | (sat_pk2(t[6], t[7], 8) << 16);
-    if (valid)
-        *(LEON_GLOBAL v2u*)(gptr_mut(pd.out) + (plane_off + (uint32_t)__mul24(y, W) + (uint32_t)x0)) = o;
 }
 
 // XCD-aware workgroup remap: hardware deals workgroups round-robin over the 8 XCDs;
@@ -466,14 +501,12 @@ __device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G,
                                                int t, char* lds, int lane)
 {
     if (t < G.tasksY) {
-        int R = div_inv(t, G.inv_gY), g = t - R * G.gY;
-        recon_group<TYPE, false>(pd, G, T, 0, R, g, lds, lane);
+        int Rt = div_inv(t, G.inv_gY), g = t - Rt * G.gY;
+        recon_task<TYPE, false>(pd, G, T, Rt, g, lds, lane);
     } else {
         t -= G.tasksY;
-        int comp = 1;
-        if (t >= G.tasksC) { t -= G.tasksC; comp = 2; }
-        int R = div_inv(t, G.inv_gC), g = t - R * G.gC;
-        recon_group<TYPE, true>(pd, G, T, comp, R, g, lds, lane);
+        int Rt = div_inv(t, G.inv_gC), g = t - Rt * G.gC;
+        recon_task<TYPE, true>(pd, G, T, Rt, g, lds, lane);
     }
 }
 
