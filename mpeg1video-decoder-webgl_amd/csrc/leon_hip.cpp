@@ -69,10 +69,9 @@ struct Staging {                 // device copy of one host-submitted picture
 }  // namespace
 
 struct leon_batch {
-    PicDesc* d_descs = nullptr;
+    PicDesc* d_descs = nullptr;   // sorted by picture type: [I..][P..][B..]
     int n = 0;
-    double bytes = 0;
-    uint64_t mbs = 0;
+    int count[3] = {0, 0, 0};     // pictures of type I, P, B
 };
 
 struct leon_decoder {
@@ -172,7 +171,8 @@ void fill_desc(const leon_decoder* d, const leon_picture& p, PicDesc& o)
     o.pad_ = 0;
 }
 
-int launch_recon(leon_decoder* d, const PicDesc* d_descs, int n, double bytes, uint64_t mbs)
+// one launch of the type-specialised kernel over n pictures of that type
+int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n)
 {
     Geom G = d->geom;
     G.n_pics = n;
@@ -186,12 +186,15 @@ int launch_recon(leon_decoder* d, const PicDesc* d_descs, int n, double bytes, u
         tl.a = get_event(d);
         tl.b = get_event(d);
         tl.kind = 0;
-        tl.bytes = bytes;
-        tl.mbs = mbs;
+        tl.mbs = (uint64_t)d->geom.mbw * d->geom.mbh * (uint64_t)n;
+        tl.bytes = algo_bytes_per_mb(type) * (double)tl.mbs;
         HIP_TRY(hipEventRecord(tl.a, d->stream));
     }
-    hipLaunchKernelGGL(k_recon, dim3(G.n_wg), dim3(64 * kWavesPerWG), kWavesPerWG * kLdsPerWave, d->stream,
-                       d_descs, G, d->d_tables);
+    const dim3 grid(G.n_wg), block(64 * kWavesPerWG);
+    const size_t lds = kWavesPerWG * kLdsPerWave;
+    if (type == LEON_PIC_I) hipLaunchKernelGGL(k_recon<1>, grid, block, lds, d->stream, d_descs, G, d->d_tables);
+    else if (type == LEON_PIC_P) hipLaunchKernelGGL(k_recon<2>, grid, block, lds, d->stream, d_descs, G, d->d_tables);
+    else hipLaunchKernelGGL(k_recon<3>, grid, block, lds, d->stream, d_descs, G, d->d_tables);
     HIP_TRY(hipGetLastError());
     if (d->timing) {
         HIP_TRY(hipEventRecord(tl.b, d->stream));
@@ -200,12 +203,27 @@ int launch_recon(leon_decoder* d, const PicDesc* d_descs, int n, double bytes, u
     return LEON_OK;
 }
 
-void batch_cost(const leon_decoder* d, const leon_picture* pics, int n, double& bytes, uint64_t& mbs)
+// descriptors sorted by type ([I..][P..][B..]); one launch per type present
+int launch_recon(leon_decoder* d, const PicDesc* d_descs, const int count[3])
 {
-    uint64_t per = (uint64_t)d->geom.mbw * d->geom.mbh;
-    bytes = 0;
-    for (int i = 0; i < n; i++) bytes += algo_bytes_per_mb(pics[i].type) * (double)per;
-    mbs = per * (uint64_t)n;
+    int at = 0;
+    for (int k = 0; k < 3; k++) {
+        if (count[k] > 0) {
+            int rc = launch_recon_type(d, k + 1, d_descs + at, count[k]);
+            if (rc != LEON_OK) return rc;
+        }
+        at += count[k];
+    }
+    return LEON_OK;
+}
+
+// fill `out` with the descriptors of pics sorted by type, and the per-type counts
+void sorted_descs(const leon_decoder* d, const leon_picture* pics, int n, PicDesc* out, int count[3])
+{
+    count[0] = count[1] = count[2] = 0;
+    for (int i = 0; i < n; i++) count[pics[i].type - 1]++;
+    int at[3] = {0, count[0], count[0] + count[1]};
+    for (int i = 0; i < n; i++) fill_desc(d, pics[i], out[at[pics[i].type - 1]++]);
 }
 
 // reserve n consecutive descriptors in the ring (wrap = wait for the previous lap)
@@ -399,12 +417,10 @@ int leon_submit_batch(leon_decoder* d, const leon_picture* pics, int32_t n, int3
     int at = 0;
     int rc = reserve_descs(d, n, at);
     if (rc != LEON_OK) return rc;
-    for (int i = 0; i < n; i++) fill_desc(d, pics[i], d->h_desc_pinned[at + i]);
+    int count[3];
+    sorted_descs(d, pics, n, d->h_desc_pinned + at, count);
     HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc) * n, hipMemcpyHostToDevice, d->stream));
-    double bytes;
-    uint64_t mbs;
-    batch_cost(d, pics, n, bytes, mbs);
-    return launch_recon(d, d->d_desc_ring + at, n, bytes, mbs);
+    return launch_recon(d, d->d_desc_ring + at, count);
 }
 
 int leon_submit_picture(leon_decoder* d, const leon_picture* pic)
@@ -446,10 +462,7 @@ int leon_submit_picture(leon_decoder* d, const leon_picture* pic)
     if (rc != LEON_OK) return rc;
     fill_desc(d, dp, d->h_desc_pinned[at]);
     HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc), hipMemcpyHostToDevice, d->stream));
-    double bytes;
-    uint64_t nmb;
-    batch_cost(d, pic, 1, bytes, nmb);
-    rc = launch_recon(d, d->d_desc_ring + at, 1, bytes, nmb);
+    rc = launch_recon_type(d, dp.type, d->d_desc_ring + at, 1);
     if (rc != LEON_OK) return rc;
     HIP_TRY(hipEventRecord(s.done, d->stream));
     s.busy = true;
@@ -465,12 +478,11 @@ int leon_batch_create(leon_decoder* d, const leon_picture* pics, int32_t n, leon
     for (int i = 0; i < n; i++) {
         int rc = check_pic(d, pics[i]);
         if (rc != LEON_OK) return rc;
-        fill_desc(d, pics[i], h[i]);
     }
     leon_batch* b = new (std::nothrow) leon_batch();
     if (!b) return fail(LEON_ERR_NOMEM, "out of host memory");
     b->n = n;
-    batch_cost(d, pics, n, b->bytes, b->mbs);
+    sorted_descs(d, pics, n, h.data(), b->count);
     if (hipMalloc(&b->d_descs, sizeof(PicDesc) * n) != hipSuccess) {
         delete b;
         return fail(LEON_ERR_NOMEM, "descriptor allocation failed");
@@ -489,7 +501,7 @@ int leon_batch_run(leon_decoder* d, const leon_batch* b)
 {
     if (!d || !b) return fail(LEON_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(d->dev));
-    return launch_recon(d, b->d_descs, b->n, b->bytes, b->mbs);
+    return launch_recon(d, b->d_descs, b->count);
 }
 
 void leon_batch_destroy(leon_decoder* d, leon_batch* b)

@@ -373,18 +373,25 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     int* const hp = reinterpret_cast<int*>(lds + kLdsCoef + b * kLdsHandoffPitch + c * 4);
     const v4i* const rp = reinterpret_cast<const v4i*>(lds + kLdsCoef + b * kLdsHandoffPitch + lo3 * 32);
 
+    v4i cv_next = {0, 0, 0, 0};
+    if (ld_ok) {
+        const int comp0 = CHROMA ? 1 : 0, R0 = CHROMA ? Rt : 2 * Rt;
+        cv_next = *(const LEON_GLOBAL v4i*)(gptr(pd.coef[comp0]) + ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)(8 * Qld)));
+    }
 #pragma unroll 1
     for (int half = 0; half < 2; half++) {
         const int comp = CHROMA ? 1 + half : 0;
         const int R = CHROMA ? Rt : 2 * Rt + half;
         const uint32_t plane_off = CHROMA ? (half == 0 ? ysz : ysz + (ysz >> 2)) : 0u;
-        const LEON_GLOBAL int16_t* coef = gptr(pd.coef[comp]);
         const int y = 8 * R + lo3;
 
-        // ---- stage 0: issue this half's loads ---------------------------------------------
-        v4i cv = {0, 0, 0, 0};
-        if (ld_ok)
-            cv = *(const LEON_GLOBAL v4i*)(coef + ((uint32_t)__mul24(8 * R + hi3, W) + (uint32_t)(8 * Qld)));
+        // ---- stage 0: this half's coefficient rows were requested a half earlier; request the
+        //      next half's now so that their HBM latency hides behind this half's arithmetic
+        const v4i cv = cv_next;
+        if (half == 0 && ld_ok) {
+            const int comp1 = CHROMA ? 2 : 0, R1 = CHROMA ? Rt : 2 * Rt + 1;
+            cv_next = *(const LEON_GLOBAL v4i*)(gptr(pd.coef[comp1]) + ((uint32_t)__mul24(8 * R1 + hi3, W) + (uint32_t)(8 * Qld)));
+        }
         RefRows rf, rb;
         if (TYPE != 1) {
             const LEON_GLOBAL uint8_t* rfw = gptr(pd.ref_fwd) + plane_off;
@@ -510,6 +517,10 @@ __device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G,
     }
 }
 
+// One kernel per picture type: the register budget of the I and P paths is not held hostage
+// by the two predictors of the B path (VGPRs decide waves per SIMD), and a launch only ever
+// contains pictures of one type.
+template <int TYPE>
 __global__ __launch_bounds__(256) void k_recon(const PicDesc* __restrict__ descs, Geom G,
                                                const Tables* __restrict__ T)
 {
@@ -521,11 +532,7 @@ __global__ __launch_bounds__(256) void k_recon(const PicDesc* __restrict__ descs
     const int t = (wg - pic * G.wg_per_pic) * kWavesPerWG + wave;
     if (t >= G.tasks_per_pic) return;
     char* lds = smem + wave * kLdsPerWave;
-    const PicDesc& pd = descs[pic];
-    const int type = pd.type;
-    if (type == 1) recon_dispatch<1>(pd, G, T, t, lds, lane);
-    else if (type == 2) recon_dispatch<2>(pd, G, T, t, lds, lane);
-    else recon_dispatch<3>(pd, G, T, t, lds, lane);
+    recon_dispatch<TYPE>(descs[pic], G, T, t, lds, lane);
 }
 
 // ---- K3: YCbCr 4:2:0 -> RGBA8 ------------------------------------------------------
