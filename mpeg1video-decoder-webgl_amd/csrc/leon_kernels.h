@@ -109,6 +109,17 @@ __device__ __forceinline__ uint32_t sat_pk2(int a, int b, uint32_t sh)
     return (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(a, b, sh) & 0xffffu;
 }
 
+// buffer resource over [p, p + 2 GiB): wave-uniform base in SGPRs, 32-bit byte offsets per lane
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p)
+{
+    return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000);
+}
+__device__ __forceinline__ v4i buf_load_v4i(const void* base, uint32_t byte_off)
+{
+    v4u r = __builtin_amdgcn_raw_buffer_load_b128(buf_rsrc(base), (int)byte_off, 0, 0);
+    return v4i{(int)r.x, (int)r.y, (int)r.z, (int)r.w};
+}
+
 // typed load at base + 32-bit byte offset: global_load with an SGPR base and a VGPR offset
 template <typename T>
 __device__ __forceinline__ T ldg(const LEON_GLOBAL void* base, uint32_t off)
@@ -218,8 +229,10 @@ __device__ __forceinline__ uint32_t avg4_u8x4(uint32_t a, uint32_t b, uint32_t c
 __device__ __forceinline__ uint32_t ref_px_clamped(const LEON_GLOBAL uint8_t* ref, uint32_t row_off, int W, int x)
 {
     int t = min(max(x >> 2, 0), (W >> 2) - 1);
-    return ref[row_off + (uint32_t)(4 * t + (x & 3))];
+    return ldg<uint8_t>(ref, row_off + (uint32_t)(4 * t + (x & 3)));
 }
+
+typedef v3u U3 __attribute__((aligned(4)));    // 12 bytes that are only dword aligned
 
 // raw reference bytes of one predictor: two rows of 12 bytes starting at the aligned
 // address below the window, plus the byte shift of the window inside them
@@ -259,8 +272,10 @@ __device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, in
     if (in_pic) {
         R.s = (uint32_t)px & 3u;
         uint32_t xo = (uint32_t)px & ~3u;
-        v3u a = *(const LEON_GLOBAL v3u*)(ref + (r0 + xo));
-        v3u c = *(const LEON_GLOBAL v3u*)(ref + (r1 + xo));
+        // buffer loads: wave-uniform descriptor in SGPRs + 32-bit offset, no 64-bit address math
+        const __amdgpu_buffer_rsrc_t rs = buf_rsrc((const void*)ref);
+        const v3u a = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(r0 + xo), 0, 0);
+        const v3u c = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(r1 + xo), 0, 0);
         R.l0 = a.x; R.l1 = a.y; R.l2 = a.z;
         R.m0 = c.x; R.m1 = c.y; R.m2 = c.z;
     } else {                                         // vector leaves the picture (rare)
@@ -331,7 +346,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     bool nopred = false;
     // per reference: window column, half-pel flags, vertical offset, base selection
     int pxA = 0, ayA = 0, ohA = 0, ovA = 0, pxB = 0, ayB = 0, ohB = 0, ovB = 0;
-    bool inA = true, inB = true, baseA_fwd = true, baseB_fwd = false;
+    bool inA = true, inB = true, usef = true, useb = true;
     if (TYPE != 1) {
         nopred = ldg<uint8_t>(gptr(pd.repadd), mb) >= 128;    // .r > 0.5
         const uint32_t mf = ldg<uint32_t>(gptr(pd.mv_fwd), mb * 4);
@@ -342,14 +357,14 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             bh = (int)(short)(mk & 0xffff);
             bv = (int)mk >> 16;
             const int dir = ldg<uint8_t>(gptr(pd.mb_dir), mb) & 3;
-            // a missing direction re-uses the other one: (p + p + 1) >> 1 == p
-            const bool usef = (dir & 1) != 0, useb = (dir & 2) != 0;
+            usef = (dir & 1) != 0;
+            useb = (dir & 2) != 0;
             nopred = nopred || dir == 0;
-            baseA_fwd = usef;
-            baseB_fwd = !useb;
-            int ah = usef ? fh : bh, av = usef ? fv : bv;
-            int ch2 = useb ? bh : fh, cv2 = useb ? bv : fv;
-            fh = ah; fv = av; bh = ch2; bv = cv2;
+            // predictor A always reads the forward reference, B the backward one (scalar bases,
+            // 32-bit offsets); an unused direction fetches with a zero vector and is replaced by
+            // the other predictor afterwards: (p + p + 1) >> 1 == p
+            if (!usef) { fh = 0; fv = 0; }
+            if (!useb) { bh = 0; bv = 0; }
         }
         {   // chroma: vector truncated toward zero first (mv_coef 0.5), then floor / parity
             int h = CHROMA ? fh / 2 : fh, v = CHROMA ? fv / 2 : fv;
@@ -376,7 +391,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     v4i cv_next = {0, 0, 0, 0};
     if (ld_ok) {
         const int comp0 = CHROMA ? 1 : 0, R0 = CHROMA ? Rt : 2 * Rt;
-        cv_next = *(const LEON_GLOBAL v4i*)(gptr(pd.coef[comp0]) + ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)(8 * Qld)));
+        cv_next = buf_load_v4i(pd.coef[comp0], 2u * ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)(8 * Qld)));
     }
 #pragma unroll 1
     for (int half = 0; half < 2; half++) {
@@ -390,14 +405,12 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         const v4i cv = cv_next;
         if (half == 0 && ld_ok) {
             const int comp1 = CHROMA ? 2 : 0, R1 = CHROMA ? Rt : 2 * Rt + 1;
-            cv_next = *(const LEON_GLOBAL v4i*)(gptr(pd.coef[comp1]) + ((uint32_t)__mul24(8 * R1 + hi3, W) + (uint32_t)(8 * Qld)));
+            cv_next = buf_load_v4i(pd.coef[comp1], 2u * ((uint32_t)__mul24(8 * R1 + hi3, W) + (uint32_t)(8 * Qld)));
         }
         RefRows rf, rb;
         if (TYPE != 1) {
-            const LEON_GLOBAL uint8_t* rfw = gptr(pd.ref_fwd) + plane_off;
-            const LEON_GLOBAL uint8_t* rbw = TYPE == 3 ? gptr(pd.ref_bwd) + plane_off : rfw;
-            rf = fetch_rows(TYPE == 3 ? (baseA_fwd ? rfw : rbw) : rfw, W, H, y, pxA, ayA, ohA, ovA, inA);
-            if (TYPE == 3) rb = fetch_rows(baseB_fwd ? rfw : rbw, W, H, y, pxB, ayB, ohB, ovB, inB);
+            rf = fetch_rows(gptr(pd.ref_fwd) + plane_off, W, H, y, pxA, ayA, ohA, ovA, inA);
+            if (TYPE == 3) rb = fetch_rows(gptr(pd.ref_bwd) + plane_off, W, H, y, pxB, ayB, ohB, ovB, inB);
         }
 
         // ---- stage 1: coefficient rows -> LDS tile [r][b][c] ------------------------------
@@ -467,8 +480,10 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             v2u pred = predict8(rf);
             if (TYPE == 3) {
                 v2u pb = predict8(rb);
-                pred.x = __builtin_amdgcn_lerp(pred.x, pb.x, 0x01010101u);
-                pred.y = __builtin_amdgcn_lerp(pred.y, pb.y, 0x01010101u);
+                v2u pf = usef ? pred : pb;
+                pb = useb ? pb : pred;
+                pred.x = __builtin_amdgcn_lerp(pf.x, pb.x, 0x01010101u);
+                pred.y = __builtin_amdgcn_lerp(pf.y, pb.y, 0x01010101u);
             }
             if (nopred) pred = v2u{0u, 0u};
             // clamp(t/256 + pred) == sat_u8((t + pred*256) >> 8)
@@ -485,7 +500,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         o.x = sat_pk2(t[0], t[1], 8) | (sat_pk2(t[2], t[3], 8) << 16);
         o.y = sat_pk2(t[4], t[5], 8) | (sat_pk2(t[6], t[7], 8) << 16);
         if (valid)
-            *(LEON_GLOBAL v2u*)(gptr_mut(pd.out) + (plane_off + (uint32_t)__mul24(y, W) + (uint32_t)x0)) = o;
+            __builtin_amdgcn_raw_buffer_store_b64(o, buf_rsrc(pd.out + plane_off), (int)((uint32_t)__mul24(y, W) + (uint32_t)x0), 0, 0);
         // the next half overwrites the LDS strip: order its writes behind this half's reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
