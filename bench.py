@@ -5,8 +5,8 @@ Workload (BASELINE.json config 4): G independent closed GOPs of a
 synthetic 1920x1080 IBBP stream (12 pictures each: I B B P B B P B B P B B in coded
 order), boundary tensors resident in HBM in the reference's own layout (dense int16
 coefficient planes + per-macroblock maps, decoders/jsv.js:1204-1298).  One "step"
-decodes all G GOPs: 5 dependency levels = 5 launches of the fused
-dequant+IDCT+MC kernel (every picture of a level, across all GOPs, in one launch),
+decodes all G GOPs: 5 dependency levels, each one launch of the fused dequant+IDCT+MC kernel
+per picture type present (8 launches: every picture of a level and type, across all GOPs),
 then one YCbCr->RGBA launch over all 12*G pictures.  value = macroblocks/s over the
 whole job (all ranks); N>1 = frame-parallel GOP shards, one process per GPU, the
 stream index broadcast once over RCCL before the timed region (weak scaling).
@@ -65,6 +65,28 @@ def build_workload(L, S, dec, torch, gops, seed):
         batches.append(dec.batch_create(pics))
     torch.cuda.synchronize()
     return batches, keep, host, gop
+
+
+def pmc_traffic(gops):
+    """HBM bytes per k_recon launch from the committed rocprofv3 PMC passes of this same workload
+    (profiles/r01c_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, WRITE_SIZE exact).
+    Counters cannot be read from inside this process, so this is the profiled figure of the
+    identical launches, scaled by the GOP count; None when the file is absent."""
+    path = os.path.join(ROOT, "profiles", "r01c_pmc.json")
+    if not os.path.exists(path):
+        return None, None
+    k = json.load(open(path))["kernels"]
+    per_type = {}
+    for t, pics_per_gop in ((1, 1), (2, 1), (3, 2)):
+        e = k.get("void leon::k_recon<%d>" % t)
+        if not e or "hbm_read_bytes_corrected" not in e:
+            return None, None
+        # the profiled launches held 48 GOPs: 48 I, 48 P, 96 B pictures
+        per_type[t] = (e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]) / (48.0 * pics_per_gop)
+    # one step = 1 I launch, 3 P launches, 4 B launches (2 B pictures per GOP each)
+    step_bytes = gops * (per_type[1] + 3 * per_type[2] + 8 * per_type[3])
+    return step_bytes / 8.0, "profiles/r01c_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 FETCH x2 correction)"
 
 
 def cpu_baseline(S, host, gop, budget_s=12.0):
@@ -184,6 +206,7 @@ def main():
     if rank == 0:
         copy_gbps = dec.measure_copy_bandwidth(1 << 31, 5)
         achieved = recon["algorithmic_bytes"] / (recon["total_ms"] * 1e-3) / 1e9 if recon["total_ms"] else 0.0
+        traffic, traffic_src = pmc_traffic(args.gops)
         out = {
             "metric": "1080p macroblocks/s", "value": value, "unit": "macroblocks/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
@@ -194,9 +217,9 @@ def main():
                        "coded": [CW, CH], "gops_per_gpu": args.gops, "pictures_per_step": pics_per_step,
                        "parallelism": "gop-shards x%d" % world, "rgba_in_step": rgba is not None},
             "fps": pics_per_step * args.steps / dt,
-            "roofline": {"bound": "hbm", "kernel": "leon::k_recon (fused dequant+IDCT+MC, all picture types)",
+            "roofline": {"bound": "hbm", "kernel": "leon::k_recon<I|P|B> (fused dequant+IDCT+MC; one launch per picture type and dependency level)",
                          "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": None, "launches": recon["launches"],
+                         "traffic": traffic, "traffic_source": traffic_src, "launches": recon["launches"],
                          "avg_launch_ms": recon["total_ms"] / max(1, recon["launches"]),
                          "algorithmic_bytes_per_launch": recon["algorithmic_bytes"] / max(1, recon["launches"]),
                          "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None},
@@ -205,7 +228,7 @@ def main():
             "stream_index_bytes": int(index["blob_bytes"]),
             "rank_checksums": crcs,
         }
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:
             cb, outs = cpu_baseline(S, host, gop)
             out["cpu_baseline"] = cb
             # the bench doubles as a parity check of the timed workload: GOP 0 against the oracle
