@@ -137,10 +137,18 @@ def main():
     import torch.distributed as dist
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs an MI355X: the reconstruction path has no CPU fallback")
+    # rehearsal knobs (a 1-GPU box cannot host two RCCL ranks): LEON_BENCH_BACKEND=gloo runs the
+    # same multi-rank code path over gloo, LEON_BENCH_ONE_DEVICE=1 puts every rank on cuda:0
+    backend = os.environ.get("LEON_BENCH_BACKEND", "nccl")
+    if os.environ.get("LEON_BENCH_ONE_DEVICE") == "1":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
     import leon_ctypes as L
     import synth as S
     import shards
@@ -187,12 +195,13 @@ def main():
     conv = dec.timing_get(1)
 
     if world > 1:
-        tmax = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        cdev = "cuda" if backend == "nccl" else "cpu"
+        tmax = torch.tensor([dt], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
         # per-rank output checksum, gathered for the report (frame-parallel shards are identical work)
         crc = torch.tensor([int(rgba[0].to(torch.int64).sum().item()) if rgba is not None else 0],
-                           dtype=torch.int64, device="cuda")
+                           dtype=torch.int64, device=cdev)
         crcs = [torch.zeros_like(crc) for _ in range(world)]
         dist.all_gather(crcs, crc)
         crcs = [int(c.item()) for c in crcs]
