@@ -1,0 +1,76 @@
+"""The headless HTML5-video-shaped facade (js/leon_player.js): event order, display re-ordering of
+B pictures, queue bound and seek -- bitstream-only on CPU, full pixels on the GPU."""
+import json
+import os
+import shutil
+import subprocess
+
+import pytest
+
+from helpers import ROOT
+
+JSDIR = os.path.join(ROOT, "mpeg1video-decoder-webgl_amd", "js")
+STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
+pytestmark = pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
+
+_SCRIPT = r"""
+const path = require('path');
+const {LeonPlayer} = require(path.join(%(js)r, 'leon_player.js'));
+const crypto = require('crypto');
+const backend = %(gpu)s ? require(path.join(%(js)r, '..', 'napi', 'leon_napi.node')) : null;
+const ev = [], shown = [];
+let maxQueue = 0;
+const p = new LeonPlayer({backend, realtime: false,
+  render: (rgba, f) => shown[shown.length - 1].rgba = crypto.createHash('sha256').update(Buffer.from(rgba.buffer, rgba.byteOffset, rgba.byteLength)).digest('hex')});
+for (const n of ['loadstart','loadedmetadata','loadeddata','canplay','canplaythrough','play','playing','pause','seeking','seeked','ended','error'])
+  p.on(n, () => ev.push(n));
+p.on('timeupdate', (e) => { maxQueue = Math.max(maxQueue, p._decodedFrames.length); });
+const orig = p._displayFrame.bind(p);
+p._displayFrame = function () { const f = p._decodedFrames[0]; if (f) shown.push({type: f.type, tr: f.temporalReference, index: f.index}); orig(); };
+p.src = %(stream)r;
+const meta = {duration: p.duration, w: p.videoWidth, h: p.videoHeight, rs: p.readyState};
+p.play();
+const first = {ended: p.ended, paused: p.paused, n: p.framesDisplayed, t: p.currentTime};
+%(extra)s
+p.destroy();
+console.log(JSON.stringify({ev, shown, meta, first, maxQueue, canPlay: [p.canPlayType('video/jsv'), p.canPlayType('video/mp4')]}));
+"""
+
+
+def _run(stream, gpu, extra=""):
+    src = _SCRIPT % {"js": JSDIR, "gpu": "true" if gpu else "false", "stream": os.path.join(STREAMS, stream), "extra": extra}
+    out = subprocess.run(["node", "-e", src], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    return json.loads(out.stdout)
+
+
+def test_events_and_display_order_bitstream_only():
+    r = _run("ibbp_96x64.jsv", gpu=False)
+    assert r["ev"][:5] == ["loadstart", "loadedmetadata", "loadeddata", "canplay", "canplaythrough"]
+    assert r["ev"][5:7] == ["play", "playing"] and r["ev"][-1] == "ended"
+    assert r["meta"]["w"] == 90 and r["meta"]["h"] == 60 and r["meta"]["rs"] == 4
+    assert r["first"] == {"ended": True, "paused": True, "n": 18, "t": r["first"]["t"]}
+    # display order = temporal reference order inside each GOP (12 + 6 pictures)
+    trs = [s["tr"] for s in r["shown"]]
+    assert trs == list(range(12)) + list(range(6))
+    assert r["maxQueue"] <= 10                      # MAX_DECODED_FRAMES (player/parts/end.js:57)
+    assert r["canPlay"] == ["probably", ""]
+
+
+def test_seek_restarts_at_the_key_entry():
+    extra = "p.currentTime = 0.6; p.play(); first.afterSeek = p.framesDisplayed;"
+    r = _run("leon_synth_352x240.jsv", gpu=False, extra=extra)
+    assert r["first"]["n"] == 24 and r["first"]["afterSeek"] == 24 + 12
+    assert "seeking" in r["ev"] and "seeked" in r["ev"] and r["ev"].count("ended") == 2
+
+
+@pytest.mark.gpu
+def test_player_pixels_match_decode_order_output():
+    """Every displayed frame's RGBA equals the frame the plain decode loop produced for it."""
+    from test_js_parser import run_cli
+    r = _run("ibbp_96x64.jsv", gpu=True)
+    dec = run_cli("decode", os.path.join(STREAMS, "ibbp_96x64.jsv"), "--rgba")
+    by_index = {i: p["rgba"] for i, p in enumerate(dec["pictures"])}
+    assert len(r["shown"]) == 18 and r["ev"][-1] == "ended"
+    for s in r["shown"]:
+        assert s["rgba"] == by_index[s["index"]], s
