@@ -191,6 +191,53 @@ __device__ __forceinline__ void butterfly8(const int (&X)[8], int (&o)[8])
     o[7] = y4 - b7;
 }
 
+// The same butterfly with X[2..7] == 0 / X[4..7] == 0 substituted (every dropped term is an exact
+// zero: 0*k + 128 divides to 0).  Chosen wave-uniformly when the higher inputs of all 64 lanes
+// are zero, which is the common case for quantised video.
+__device__ __forceinline__ void butterfly8_lo2(int X0, int X1, int (&o)[8])
+{
+    const int c128 = 128;
+    int x4 = div256(mad24k(X1, 473, c128)) - X1;
+    int x0 = x4 - div256(mad24k(X1, 362, c128));
+    int y7 = -x0 - div256(mad24k(X1, 196, c128));
+    o[0] = X1 + X0;
+    o[1] = x4 + X0;
+    o[2] = X0 - x0;
+    o[3] = X0 - y7;
+    o[4] = X0 + y7;
+    o[5] = x0 + X0;
+    o[6] = X0 - x4;
+    o[7] = X0 - X1;
+}
+__device__ __forceinline__ void butterfly8_lo4(int X0, int X1, int X2, int X3, int (&o)[8])
+{
+    const int c128 = 128;
+    int b7 = X1 + X3;
+    int x4 = div256(mad24k(X1, 473, mad24k(X3, 196, c128))) - b7;
+    int x0 = x4 - div256(mad24k(X1 - X3, 362, c128));
+    int x2 = div256(mad24k(X2, 362, c128)) - X2;
+    int y3 = X0 + x2;
+    int y4 = X0 + X2;
+    int y5 = X0 - x2;
+    int y6 = X0 - X2;
+    int y7 = -x0 - div256(mad24k(X3, -473, mad24k(X1, 196, c128)));
+    o[0] = b7 + y4;
+    o[1] = x4 + y3;
+    o[2] = y5 - x0;
+    o[3] = y6 - y7;
+    o[4] = y6 + y7;
+    o[5] = x0 + y5;
+    o[6] = y3 - x4;
+    o[7] = y4 - b7;
+}
+// dispatch on the number of leading inputs that can be non-zero (wave-uniform)
+__device__ __forceinline__ void butterfly8_n(const int (&X)[8], int n_live, int (&o)[8])
+{
+    if (n_live <= 2) butterfly8_lo2(X[0], X[1], o);
+    else if (n_live <= 4) butterfly8_lo4(X[0], X[1], X[2], X[3], o);
+    else butterfly8(X, o);
+}
+
 // COL_INT_3 for one NON-ZERO coefficient.  qO = quantiser_scale * matrix entry,
 // pm = premultiplier, nim = -1 for a non-intra block, 0 for an intra block.
 __device__ __forceinline__ int dequant_nz(int X, int qO, int pm, int nim, int lo2048, int hi2047)
@@ -429,21 +476,31 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
 #pragma unroll
             for (int m = 0; m < 8; m++) t[m] = 128;
         } else {
+            // which coefficient columns are live anywhere in the wave: lane (b,c) -> bit c
+            uint64_t colbits = __builtin_amdgcn_ballot_w64(any != 0);
+            colbits |= colbits >> 32;
+            colbits |= colbits >> 16;
+            colbits |= colbits >> 8;
+            const int cols_live = 32 - __builtin_clz((uint32_t)(colbits & 0xffu) | 1u);
             // ---- stage 2: column pass ------------------------------------------------------
             const int dc = X[0];
             const int lo2048 = -2048, hi2047 = 2047;
+            int rows_live = 1;                            // wave-uniform: 1 + highest row with a non-zero
 #pragma unroll
             for (int i = 0; i < 8; i++) {
                 // zeros stay zero (the shader's `continue`): lanes with a zero sit the block out,
                 // and a row whose 64 coefficients are all zero costs one compare and a branch
-                if (X[i] != 0) {
-                    int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
-                    X[i] = dequant_nz(X[i], (int)qow[i], P, nim, lo2048, hi2047);
+                if (__builtin_amdgcn_ballot_w64(X[i] != 0) != 0) {
+                    rows_live = i + 1;
+                    if (X[i] != 0) {
+                        int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
+                        X[i] = dequant_nz(X[i], (int)qow[i], P, nim, lo2048, hi2047);
+                    }
                 }
             }
             if (dc_lane) X[0] = dc * 256;                 // COL_4 / COL_INT_31
             int v[8];
-            butterfly8(X, v);
+            butterfly8_n(X, rows_live, v);
             // floor( float(v) * _y ), then int( w / _y ) == trunc(5w/2) == trunc(w * 2.5f)
             float wf[8];
 #pragma unroll
@@ -467,9 +524,11 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
             // ---- stage 3: row pass ---------------------------------------------------------
-            v4i w0 = rp[0], w1 = rp[1];
+            // columns that were all zero in every block give zero inputs here (wave-uniform)
+            v4i w0 = rp[0], w1 = {0, 0, 0, 0};
+            if (cols_live > 4) w1 = rp[1];
             int Y[8] = {w0.x + 128, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};   // "+128" of (t+128)/256
-            butterfly8(Y, t);
+            butterfly8_n(Y, cols_live, t);
             // t/256 truncating == arithmetic shift after adding 255 to negative values
 #pragma unroll
             for (int m = 0; m < 8; m++) t[m] += (t[m] >> 31) & 255;
