@@ -143,8 +143,16 @@ int leon_write_planes(leon_decoder* d, int32_t slot, const uint8_t* y, const uin
 /* device address of a slot's [Y|Cb|Cr] planes (for zero-copy consumers) */
 int leon_slot_device_ptr(leon_decoder* d, int32_t slot, void** ptr, size_t* bytes);
 
-/* wait for everything submitted so far */
+/* wait for everything submitted so far (both streams, see leon_set_overlap_convert) */
 int leon_sync(leon_decoder* d);
+
+/* Overlap display conversion with reconstruction: when on, leon_convert_rgba_batch with a device
+ * destination runs on a second HIP stream, ordered after the reconstruction work submitted so
+ * far, and the following submits do not wait for it -- unless one of them writes a slot whose
+ * conversion is still pending, in which case the library orders it behind that conversion.
+ * (The reference has one GL queue; this is the MI355X-side equivalent of its decode-ahead while
+ * requestAnimationFrame renders, player/easybits.player.js:2478-2504.)  Default: off. */
+int leon_set_overlap_convert(leon_decoder* d, int32_t on);
 
 /* HIP-event timing of the kernels launched by this decoder (bench.py roofline).
  * kind: 0 = reconstruction kernel (dequant+IDCT+MC), 1 = colour conversion. */

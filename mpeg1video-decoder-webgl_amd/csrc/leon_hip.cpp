@@ -72,6 +72,7 @@ struct leon_batch {
     PicDesc* d_descs = nullptr;   // sorted by picture type: [I..][P..][B..]
     int n = 0;
     int count[3] = {0, 0, 0};     // pictures of type I, P, B
+    std::vector<int32_t> out_slots;
 };
 
 struct leon_decoder {
@@ -79,6 +80,12 @@ struct leon_decoder {
     int dev = 0;
     hipStream_t stream = nullptr;
     bool own_stream = false;
+    // display conversion overlapped with reconstruction (leon_set_overlap_convert)
+    bool overlap_convert = false;
+    hipStream_t conv_stream = nullptr;
+    hipEvent_t ev_recon_done = nullptr;   // recorded on `stream`, waited on by conv_stream
+    hipEvent_t ev_conv_done = nullptr;    // recorded on conv_stream after each conversion
+    std::vector<uint8_t> conv_pending;    // per slot: a conversion may still be reading it
     Geom geom{};
     size_t plane_bytes = 0;      // cw*ch*3/2
     size_t slot_stride = 0;      // padded
@@ -169,6 +176,19 @@ void fill_desc(const leon_decoder* d, const leon_picture& p, PicDesc& o)
     o.ref_bwd = p.type == LEON_PIC_B ? d->d_slots + (size_t)p.ref_bwd_slot * d->slot_stride : nullptr;
     o.type = p.type;
     o.pad_ = 0;
+}
+
+// a submit that overwrites a slot still being converted on the second stream waits for it
+int guard_pending_conversions(leon_decoder* d, const int32_t* out_slots, int n)
+{
+    if (!d->overlap_convert || d->conv_pending.empty()) return LEON_OK;
+    bool hit = false;
+    for (int i = 0; i < n && !hit; i++) hit = d->conv_pending[out_slots[i]] != 0;
+    if (hit) {
+        HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_conv_done, 0));
+        std::fill(d->conv_pending.begin(), d->conv_pending.end(), 0);
+    }
+    return LEON_OK;
 }
 
 // one launch of the type-specialised kernel over n pictures of that type
@@ -342,6 +362,12 @@ void leon_destroy(leon_decoder* d)
     if (d->d_slot_ids) hipFree(d->d_slot_ids);
     if (d->h_slot_ids) hipHostFree(d->h_slot_ids);
     if (d->d_rgba_tmp) hipFree(d->d_rgba_tmp);
+    if (d->conv_stream) {
+        hipStreamSynchronize(d->conv_stream);
+        hipStreamDestroy(d->conv_stream);
+        hipEventDestroy(d->ev_recon_done);
+        hipEventDestroy(d->ev_conv_done);
+    }
     if (d->own_stream && d->stream) hipStreamDestroy(d->stream);
     delete d;
 }
@@ -417,6 +443,12 @@ int leon_submit_batch(leon_decoder* d, const leon_picture* pics, int32_t n, int3
     int at = 0;
     int rc = reserve_descs(d, n, at);
     if (rc != LEON_OK) return rc;
+    {
+        std::vector<int32_t> outs(n);
+        for (int i = 0; i < n; i++) outs[i] = pics[i].out_slot;
+        rc = guard_pending_conversions(d, outs.data(), n);
+        if (rc != LEON_OK) return rc;
+    }
     int count[3];
     sorted_descs(d, pics, n, d->h_desc_pinned + at, count);
     HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc) * n, hipMemcpyHostToDevice, d->stream));
@@ -461,6 +493,8 @@ int leon_submit_picture(leon_decoder* d, const leon_picture* pic)
     rc = reserve_descs(d, 1, at);
     if (rc != LEON_OK) return rc;
     fill_desc(d, dp, d->h_desc_pinned[at]);
+    rc = guard_pending_conversions(d, &dp.out_slot, 1);
+    if (rc != LEON_OK) return rc;
     HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc), hipMemcpyHostToDevice, d->stream));
     rc = launch_recon_type(d, dp.type, d->d_desc_ring + at, 1);
     if (rc != LEON_OK) return rc;
@@ -483,6 +517,8 @@ int leon_batch_create(leon_decoder* d, const leon_picture* pics, int32_t n, leon
     if (!b) return fail(LEON_ERR_NOMEM, "out of host memory");
     b->n = n;
     sorted_descs(d, pics, n, h.data(), b->count);
+    b->out_slots.resize(n);
+    for (int i = 0; i < n; i++) b->out_slots[i] = pics[i].out_slot;
     if (hipMalloc(&b->d_descs, sizeof(PicDesc) * n) != hipSuccess) {
         delete b;
         return fail(LEON_ERR_NOMEM, "descriptor allocation failed");
@@ -501,6 +537,8 @@ int leon_batch_run(leon_decoder* d, const leon_batch* b)
 {
     if (!d || !b) return fail(LEON_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(d->dev));
+    int rc = guard_pending_conversions(d, b->out_slots.data(), b->n);
+    if (rc != LEON_OK) return rc;
     return launch_recon(d, b->d_descs, b->count);
 }
 
@@ -525,12 +563,19 @@ int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, vo
         if (slots[i] < 0 || slots[i] >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "slot %d", slots[i]);
     if (d->slot_id_head + n > leon_decoder::kSlotIdRing) {
         HIP_TRY(hipStreamSynchronize(d->stream));
+        if (d->conv_stream) HIP_TRY(hipStreamSynchronize(d->conv_stream));
         d->slot_id_head = 0;
     }
     int at = d->slot_id_head;
     d->slot_id_head += n;
     memcpy(d->h_slot_ids + at, slots, sizeof(int32_t) * n);
-    HIP_TRY(hipMemcpyAsync(d->d_slot_ids + at, d->h_slot_ids + at, sizeof(int32_t) * n, hipMemcpyHostToDevice, d->stream));
+    hipStream_t cs = d->stream;
+    if (d->overlap_convert) {      // second stream, ordered behind the reconstruction submitted so far
+        cs = d->conv_stream;
+        HIP_TRY(hipEventRecord(d->ev_recon_done, d->stream));
+        HIP_TRY(hipStreamWaitEvent(cs, d->ev_recon_done, 0));
+    }
+    HIP_TRY(hipMemcpyAsync(d->d_slot_ids + at, d->h_slot_ids + at, sizeof(int32_t) * n, hipMemcpyHostToDevice, cs));
     RgbaGeom G{};
     G.cw = d->cfg.coded_width;
     G.ch = d->cfg.coded_height;
@@ -549,27 +594,31 @@ int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, vo
         tl.kind = 1;
         tl.mbs = (uint64_t)d->geom.mbw * d->geom.mbh * n;
         tl.bytes = kRgbaBytesPerMb * (double)tl.mbs;
-        HIP_TRY(hipEventRecord(tl.a, d->stream));
+        HIP_TRY(hipEventRecord(tl.a, cs));
     }
     if (flavour == LEON_RGB_CPU_TWIN) {
         if ((G.fw & 1) || (G.fh & 1)) {   // bytes the quad loop never reaches stay 255 (fillArray)
             size_t nd = (size_t)G.fw * G.fh * n;
-            hipLaunchKernelGGL(k_fill255, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, d->stream, (uint32_t*)rgba_device, nd);
+            hipLaunchKernelGGL(k_fill255, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, cs, (uint32_t*)rgba_device, nd);
         }
         if (G.cols > 0 && G.rows > 0 && (G.fw & 7) == 0 && ((size_t)rgba_device & 15) == 0)
-            hipLaunchKernelGGL(k_rgba_twin8, dim3((G.fw / 8 + 63) / 64, G.rows, n), dim3(64), 0, d->stream,
+            hipLaunchKernelGGL(k_rgba_twin8, dim3((G.fw / 8 + 63) / 64, G.rows, n), dim3(64), 0, cs,
                                d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
         else if (G.cols > 0 && G.rows > 0)
-            hipLaunchKernelGGL(k_rgba_twin, dim3((G.cols + 255) / 256, G.rows, n), dim3(256), 0, d->stream,
+            hipLaunchKernelGGL(k_rgba_twin, dim3((G.cols + 255) / 256, G.rows, n), dim3(256), 0, cs,
                                d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
     } else {
-        hipLaunchKernelGGL(k_rgba_gl, dim3((G.fw + 255) / 256, G.fh, n), dim3(256), 0, d->stream,
+        hipLaunchKernelGGL(k_rgba_gl, dim3((G.fw + 255) / 256, G.fh, n), dim3(256), 0, cs,
                            d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
     }
     HIP_TRY(hipGetLastError());
     if (d->timing) {
-        HIP_TRY(hipEventRecord(tl.b, d->stream));
+        HIP_TRY(hipEventRecord(tl.b, cs));
         d->timed.push_back(tl);
+    }
+    if (d->overlap_convert) {
+        HIP_TRY(hipEventRecord(d->ev_conv_done, cs));
+        for (int i = 0; i < n; i++) d->conv_pending[slots[i]] = 1;
     }
     return LEON_OK;
 }
@@ -581,7 +630,10 @@ int leon_convert_rgba(leon_decoder* d, int32_t slot, void* rgba, int32_t dst_mem
     HIP_TRY(hipSetDevice(d->dev));
     size_t bytes = (size_t)d->cfg.frame_width * d->cfg.frame_height * 4;
     if (!d->d_rgba_tmp) HIP_TRY(hipMalloc(&d->d_rgba_tmp, bytes));
+    const bool ov = d->overlap_convert;
+    d->overlap_convert = false;                 // host destination: plain in-order path
     int rc = leon_convert_rgba_batch(d, &slot, 1, d->d_rgba_tmp, flavour);
+    d->overlap_convert = ov;
     if (rc != LEON_OK) return rc;
     HIP_TRY(hipMemcpyAsync(rgba, d->d_rgba_tmp, bytes, hipMemcpyDeviceToHost, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
@@ -627,6 +679,25 @@ int leon_sync(leon_decoder* d)
     if (!d) return fail(LEON_ERR_INVALID, "null decoder");
     HIP_TRY(hipSetDevice(d->dev));
     HIP_TRY(hipStreamSynchronize(d->stream));
+    if (d->conv_stream) {
+        HIP_TRY(hipStreamSynchronize(d->conv_stream));
+        std::fill(d->conv_pending.begin(), d->conv_pending.end(), 0);
+    }
+    return LEON_OK;
+}
+
+int leon_set_overlap_convert(leon_decoder* d, int32_t on)
+{
+    if (!d) return fail(LEON_ERR_INVALID, "null decoder");
+    HIP_TRY(hipSetDevice(d->dev));
+    if (on && !d->conv_stream) {
+        HIP_TRY(hipStreamCreateWithFlags(&d->conv_stream, hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&d->ev_recon_done, hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&d->ev_conv_done, hipEventDisableTiming));
+        d->conv_pending.assign(d->cfg.n_slots, 0);
+    }
+    if (!on && d->conv_stream) HIP_TRY(hipStreamSynchronize(d->conv_stream));
+    d->overlap_convert = on != 0;
     return LEON_OK;
 }
 
@@ -642,6 +713,7 @@ int leon_timing_reset(leon_decoder* d)
     if (!d) return fail(LEON_ERR_INVALID, "null decoder");
     HIP_TRY(hipSetDevice(d->dev));
     HIP_TRY(hipStreamSynchronize(d->stream));
+    if (d->conv_stream) HIP_TRY(hipStreamSynchronize(d->conv_stream));
     for (auto& t : d->timed) {
         d->ev_pool.push_back(t.a);
         d->ev_pool.push_back(t.b);
@@ -655,6 +727,7 @@ int leon_timing_get(leon_decoder* d, int32_t kind, leon_kernel_stats* out)
     if (!d || !out) return fail(LEON_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(d->dev));
     HIP_TRY(hipStreamSynchronize(d->stream));
+    if (d->conv_stream) HIP_TRY(hipStreamSynchronize(d->conv_stream));
     leon_kernel_stats s{};
     for (auto& t : d->timed) {
         if (t.kind != kind) continue;

@@ -24,7 +24,7 @@ SYMBOLS = [
     "leon_acquire_slot", "leon_release_slot", "leon_free_decoded_slots", "leon_submit_picture",
     "leon_submit_batch", "leon_batch_create", "leon_batch_run", "leon_batch_destroy",
     "leon_convert_rgba", "leon_convert_rgba_batch", "leon_read_planes", "leon_write_planes",
-    "leon_slot_device_ptr", "leon_sync", "leon_timing_enable", "leon_timing_reset", "leon_timing_get",
+    "leon_slot_device_ptr", "leon_sync", "leon_set_overlap_convert", "leon_timing_enable", "leon_timing_reset", "leon_timing_get",
     "leon_measure_copy_bandwidth",
 ]
 
@@ -94,6 +94,7 @@ def load():
     lib.leon_write_planes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.leon_slot_device_ptr.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.leon_sync.argtypes = [C.c_void_p]
+    lib.leon_set_overlap_convert.argtypes = [C.c_void_p, C.c_int32]
     lib.leon_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.leon_timing_reset.argtypes = [C.c_void_p]
     lib.leon_timing_get.argtypes = [C.c_void_p, C.c_int32, C.POINTER(KernelStats)]
@@ -226,6 +227,9 @@ class Decoder:
 
     def sync(self):
         _chk(self.lib.leon_sync(self.h))
+
+    def set_overlap_convert(self, on=True):
+        _chk(self.lib.leon_set_overlap_convert(self.h, 1 if on else 0))
 
     def timing_enable(self, on=True):
         _chk(self.lib.leon_timing_enable(self.h, 1 if on else 0))

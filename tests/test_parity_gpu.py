@@ -298,3 +298,34 @@ def test_device_batch_equals_single_submits_1080p(L, O, S):
         assert np.array_equal(single[1], exp)
     finally:
         dec.close()
+
+
+def test_overlapped_conversion_is_ordered_against_slot_reuse(L, O, S):
+    """leon_set_overlap_convert: the RGBA conversion runs on a second stream; a later submit that
+    overwrites a slot still being converted must wait for it."""
+    import torch
+    cw, ch = 352, 240
+    rng = np.random.default_rng(11)
+    first = [S.make_picture(rng, cw, ch, S.PIC_I) for _ in range(6)]
+    second = [S.make_picture(rng, cw, ch, S.PIC_I) for _ in range(6)]
+    dec = L.Decoder(cw, ch, n_slots=6)
+    try:
+        dec.set_overlap_convert(True)
+        keep = []
+        for i, t in enumerate(first):
+            t["slot"], t["ref_fwd"], t["ref_bwd"] = i, None, None
+            hip_submit(L, dec, t, keep)
+        out = torch.zeros((6, ch, cw, 4), dtype=torch.uint8, device="cuda")
+        for rep in range(3):                    # several rounds to give a race a chance to show
+            dec.convert_rgba_batch(np.arange(6, dtype=np.int32), out.data_ptr())
+            for i, t in enumerate(second if rep % 2 == 0 else first):
+                t["slot"], t["ref_fwd"], t["ref_bwd"] = i, None, None
+                hip_submit(L, dec, t, keep)
+            dec.sync()
+            src = first if rep % 2 == 0 else second
+            got = out.cpu().numpy()
+            for i, t in enumerate(src):
+                planes = O.split_planes(O.decode_picture(1, cw, ch, t["coef_y"], t["coef_cb"], t["coef_cr"], t["qscale"], t["intra"]), cw, ch)
+                assert np.array_equal(got[i], O.ycbcr_to_rgba(*planes, cw, cw, ch, "cpu")), (rep, i)
+    finally:
+        dec.close()
