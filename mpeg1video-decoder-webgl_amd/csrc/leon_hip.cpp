@@ -9,6 +9,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <cstdlib>
 #include <new>
 #include <string>
 #include <vector>
@@ -211,7 +212,9 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n)
         HIP_TRY(hipEventRecord(tl.a, d->stream));
     }
     const dim3 grid(G.n_wg), block(64 * kWavesPerWG);
-    const size_t lds = kWavesPerWG * kLdsPerWave;
+    // LEON_DEBUG_LDS_PAD (bytes): extra dynamic LDS per workgroup = an occupancy throttle for experiments
+    static const size_t lds_pad = getenv("LEON_DEBUG_LDS_PAD") ? (size_t)atol(getenv("LEON_DEBUG_LDS_PAD")) : 0;
+    const size_t lds = kWavesPerWG * kLdsPerWave + lds_pad;
     if (type == LEON_PIC_I) hipLaunchKernelGGL(k_recon<1>, grid, block, lds, d->stream, d_descs, G, d->d_tables);
     else if (type == LEON_PIC_P) hipLaunchKernelGGL(k_recon<2>, grid, block, lds, d->stream, d_descs, G, d->d_tables);
     else hipLaunchKernelGGL(k_recon<3>, grid, block, lds, d->stream, d_descs, G, d->d_tables);
