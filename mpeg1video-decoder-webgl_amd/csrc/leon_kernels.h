@@ -119,6 +119,25 @@ __device__ __forceinline__ v4i buf_load_v4i(const void* base, uint32_t byte_off)
     v4u r = __builtin_amdgcn_raw_buffer_load_b128(buf_rsrc(base), (int)byte_off, 0, 0);
     return v4i{(int)r.x, (int)r.y, (int)r.z, (int)r.w};
 }
+// Lanes that must not touch memory carry this bit in their 32-bit buffer offset: it is past
+// num_records of every resource above, so the load returns 0 and the store is dropped by the
+// bounds check -- no exec-mask branch around the instruction, and the number of outstanding
+// memory operations stays a compile-time constant (precise s_waitcnt counts instead of 0).
+constexpr uint32_t kOobBit = 0x80000000u;
+// per-lane offset + wave-uniform offset (the scalar part is not range checked)
+__device__ __forceinline__ v4i buf_load_v4i_s(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+{
+    v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, 0);
+    return v4i{(int)r.x, (int)r.y, (int)r.z, (int)r.w};
+}
+// lanes whose value is non-zero, as a scalar mask: ONE v_cmp (the ballot builtin on a
+// 16-bit-derived compare costs three vector instructions with this compiler)
+__device__ __forceinline__ uint64_t lanes_nonzero(int v)
+{
+    uint64_t m;
+    asm("v_cmp_ne_u32_e64 %0, 0, %1" : "=s"(m) : "v"(v));
+    return m;
+}
 
 // typed load at base + 32-bit byte offset: global_load with an SGPR base and a VGPR offset
 template <typename T>
@@ -246,6 +265,19 @@ __device__ __forceinline__ int dequant_nz(int X, int qO, int pm, int nim, int lo
     int t = mul24_asm(x2, qO);                        // |x2| < 2^17, qO < 2^13
     int f = t >> 4;                                   // floor(./16)
     f = (f - med3_asm(f, 0, 1)) | 1;                  // even -> toward zero; 0 -> +1
+    f = med3_asm(f, lo2048, hi2047);
+    return __mul24(f, pm);
+}
+// The same for a coefficient that may be zero, branch-free: sign(X) & 1 replaces the constant 1
+// of the oddification, so X == 0 gives 0*q -> 0 - 0 -> | 0 -> 0 (the shader's `continue`),
+// and every X != 0 takes exactly the path above.
+__device__ __forceinline__ int dequant_any(int X, int qO, int pm, int nim, int lo2048, int hi2047)
+{
+    const int sg = sign3(X);
+    int x2 = (X << 1) + (sg & nim);
+    int t = mul24_asm(x2, qO);
+    int f = t >> 4;
+    f = (f - med3_asm(f, 0, 1)) | (sg & 1);
     f = med3_asm(f, lo2048, hi2047);
     return __mul24(f, pm);
 }
@@ -381,7 +413,12 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     // ---- shared prologue ----------------------------------------------------------------
     const int Qld = g * 8 + lo3;                      // stage-1 role: lane (r = hi3, b = lo3)
     const bool ld_ok = Qld < bw;
-    const int b = hi3;                                // afterwards: lane (b, c = lo3) / (b, n = lo3)
+    // afterwards: lane (c = hi3, b = lo3) in the column pass and (n = hi3, b = lo3) in the row
+    // pass: the 8 lanes of an aligned group hold the 8 blocks of ONE sample row, so the
+    // reference fetches and the stores of a group are contiguous along a picture row and the
+    // texture addresser merges them into 64-byte accesses (with rows across adjacent lanes every
+    // lane was its own L1 access, and the vector L1 -- one access per clock -- was the limiter)
+    const int b = lo3;
     const int Qb = g * 8 + b;
     const bool valid = Qb < bw;
     const int Qs = valid ? Qb : bw - 1;
@@ -389,7 +426,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     const int q = ldg<uint8_t>(gptr(pd.qscale), mb) & 31;
     const bool ia = ldg<uint8_t>(gptr(pd.intra), mb) != 0;   // I pictures honour the map too (COL_3)
     const int x0 = 8 * Qs;
-    const int c = lo3;
+    const int c = hi3;
     bool nopred = false;
     // per reference: window column, half-pel flags, vertical offset, base selection
     int pxA = 0, ayA = 0, ohA = 0, ovA = 0, pxB = 0, ayB = 0, ohB = 0, ovB = 0;
@@ -428,31 +465,34 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     const v4u qoA = ldg<v4u>(T, qoff), qoB = ldg<v4u>(T, qoff + 16u);
     const v2u pm8 = ldg<v2u>(T, (uint32_t)sizeof(T->qO) + (uint32_t)c * 8u);
     const uint32_t qow[8] = {qoA.x, qoA.y, qoA.z, qoA.w, qoB.x, qoB.y, qoB.z, qoB.w};
-    const int nim = ia ? 0 : -1;
+    int nim = ia ? 0 : -1;
+    asm("" : "+v"(nim));                              // keep it a mask (v_and), not a select
     const bool dc_lane = c == 0 && ia;
     char* const lds_wr = lds + hi3 * 128 + lo3 * 16;
     const char* const lds_col = lds + b * 16 + c * 2;
     int* const hp = reinterpret_cast<int*>(lds + kLdsCoef + b * kLdsHandoffPitch + c * 4);
-    const v4i* const rp = reinterpret_cast<const v4i*>(lds + kLdsCoef + b * kLdsHandoffPitch + lo3 * 32);
+    const v4i* const rp = reinterpret_cast<const v4i*>(lds + kLdsCoef + b * kLdsHandoffPitch + hi3 * 32);
 
-    v4i cv_next = {0, 0, 0, 0};
-    if (ld_ok) {
-        const int comp0 = CHROMA ? 1 : 0, R0 = CHROMA ? Rt : 2 * Rt;
-        cv_next = buf_load_v4i(pd.coef[comp0], 2u * ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)(8 * Qld)));
-    }
-#pragma unroll 1
+    // per-lane offsets of the task's first half; the second half differs by a scalar
+    const int R0 = CHROMA ? Rt : 2 * Rt;
+    const uint32_t coef_voff = (2u * ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)(8 * Qld))) | (ld_ok ? 0u : kOobBit);
+    const uint32_t out_voff = ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)x0) | (valid ? 0u : kOobBit);
+    const uint32_t half_step = CHROMA ? 0u : 8u * (uint32_t)W;   // luma: next block row; chroma: next plane
+    v4i cv_next = buf_load_v4i_s(buf_rsrc(pd.coef[CHROMA ? 1 : 0]), coef_voff, 0u);
+#pragma unroll
     for (int half = 0; half < 2; half++) {
         const int comp = CHROMA ? 1 + half : 0;
         const int R = CHROMA ? Rt : 2 * Rt + half;
         const uint32_t plane_off = CHROMA ? (half == 0 ? ysz : ysz + (ysz >> 2)) : 0u;
-        const int y = 8 * R + lo3;
+        const int y = 8 * R + hi3;
 
         // ---- stage 0: this half's coefficient rows were requested a half earlier; request the
         //      next half's now so that their HBM latency hides behind this half's arithmetic
         const v4i cv = cv_next;
-        if (half == 0 && ld_ok) {
-            const int comp1 = CHROMA ? 2 : 0, R1 = CHROMA ? Rt : 2 * Rt + 1;
-            cv_next = buf_load_v4i(pd.coef[comp1], 2u * ((uint32_t)__mul24(8 * R1 + hi3, W) + (uint32_t)(8 * Qld)));
+        {   // always issued; in the last half the resource has no records, so nothing is fetched
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)pd.coef[CHROMA ? 2 : 0], 0, half == 0 ? 0x7fffffff : 0, 0x00020000);
+            cv_next = buf_load_v4i_s(rs, coef_voff, 2u * half_step);
         }
         RefRows rf, rb;
         if (TYPE != 1) {
@@ -470,32 +510,29 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         int X[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) X[i] = *reinterpret_cast<const short*>(lds_col + i * 128);
-        const int any = (X[0] | X[1] | X[2]) | (X[3] | X[4] | X[5]) | (X[6] | X[7]);
-        if (__builtin_amdgcn_ballot_w64(any != 0) == 0) {
+        uint64_t nz[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) nz[i] = lanes_nonzero(X[i]);
+        uint64_t colbits = (nz[0] | nz[1]) | (nz[2] | nz[3]) | (nz[4] | nz[5]) | (nz[6] | nz[7]);
+        if (colbits == 0) {
             // no coefficient in any of the 8 blocks: residual 0 = (0 + 128) / 256
 #pragma unroll
             for (int m = 0; m < 8; m++) t[m] = 128;
         } else {
-            // which coefficient columns are live anywhere in the wave: lane (b,c) -> bit c
-            uint64_t colbits = __builtin_amdgcn_ballot_w64(any != 0);
-            colbits |= colbits >> 32;
-            colbits |= colbits >> 16;
-            colbits |= colbits >> 8;
-            const int cols_live = 32 - __builtin_clz((uint32_t)(colbits & 0xffu) | 1u);
+            // which coefficient columns are live anywhere in the wave: lane (c,b) -> byte c of the mask
+            const int cols_live = 8 - (__builtin_clzll(colbits | 1ull) >> 3);
             // ---- stage 2: column pass ------------------------------------------------------
             const int dc = X[0];
             const int lo2048 = -2048, hi2047 = 2047;
             int rows_live = 1;                            // wave-uniform: 1 + highest row with a non-zero
 #pragma unroll
             for (int i = 0; i < 8; i++) {
-                // zeros stay zero (the shader's `continue`): lanes with a zero sit the block out,
-                // and a row whose 64 coefficients are all zero costs one compare and a branch
-                if (__builtin_amdgcn_ballot_w64(X[i] != 0) != 0) {
+                // a row whose 64 coefficients are all zero costs its compare and a scalar branch;
+                // in a live row every lane runs the branch-free form (zeros stay zero)
+                if (nz[i] != 0) {
                     rows_live = i + 1;
-                    if (X[i] != 0) {
-                        int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
-                        X[i] = dequant_nz(X[i], (int)qow[i], P, nim, lo2048, hi2047);
-                    }
+                    int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
+                    X[i] = dequant_any(X[i], (int)qow[i], P, nim, lo2048, hi2047);
                 }
             }
             if (dc_lane) X[0] = dc * 256;                 // COL_4 / COL_INT_31
@@ -558,8 +595,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         v2u o;
         o.x = sat_pk2(t[0], t[1], 8) | (sat_pk2(t[2], t[3], 8) << 16);
         o.y = sat_pk2(t[4], t[5], 8) | (sat_pk2(t[6], t[7], 8) << 16);
-        if (valid)
-            __builtin_amdgcn_raw_buffer_store_b64(o, buf_rsrc(pd.out + plane_off), (int)((uint32_t)__mul24(y, W) + (uint32_t)x0), 0, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(o, buf_rsrc(pd.out + plane_off), (int)out_voff, (int)(half ? half_step : 0u), 0);
         // the next half overwrites the LDS strip: order its writes behind this half's reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
