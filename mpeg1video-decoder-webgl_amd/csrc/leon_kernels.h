@@ -339,8 +339,13 @@ __device__ __forceinline__ void gather9_slow(const LEON_GLOBAL uint8_t* ref, uin
 
 // Issue the loads of one predictor: rows y+ay and y+ay+ov, window columns px..px+8.
 // px / oh / ov / in_pic come from the task prologue (shared by both halves).
+// The lanes (n, b) and (n+1, b) belong to the same block, hence to the same vector: the lower
+// row of lane n IS the upper row of lane n+1.  Only the upper row is fetched by every lane;
+// the ninth row of a block is fetched by its n == 7 lanes alone (all other lanes carry the
+// out-of-range offset, which costs no cache access), and finish_rows() moves the rest
+// between lanes.  That halves the L1 accesses of the reference fetch.
 __device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, int W, int H, int y,
-                                              int px, int ay, int oh, int ov, bool in_pic)
+                                              int px, int ay, int oh, int ov, bool in_pic, bool last_row)
 {
     int py0 = min(max(y + ay, 0), H - 1);
     int py1 = min(max(y + ay + ov, 0), H - 1);
@@ -348,21 +353,33 @@ __device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, in
     uint32_t r1 = (uint32_t)__mul24(py1, W);
     RefRows R;
     R.oh = (uint32_t)oh;
+    R.m0 = R.m1 = R.m2 = 0;
     if (in_pic) {
         R.s = (uint32_t)px & 3u;
         uint32_t xo = (uint32_t)px & ~3u;
         // buffer loads: wave-uniform descriptor in SGPRs + 32-bit offset, no 64-bit address math
         const __amdgpu_buffer_rsrc_t rs = buf_rsrc((const void*)ref);
         const v3u a = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(r0 + xo), 0, 0);
-        const v3u c = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(r1 + xo), 0, 0);
+        const v3u c = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)((r1 + xo) | (last_row && ov ? 0u : kOobBit)), 0, 0);
         R.l0 = a.x; R.l1 = a.y; R.l2 = a.z;
         R.m0 = c.x; R.m1 = c.y; R.m2 = c.z;
     } else {                                         // vector leaves the picture (rare)
         R.s = 0;
         gather9_slow(ref, r0, W, px, R.l0, R.l1, R.l2);
-        gather9_slow(ref, r1, W, px, R.m0, R.m1, R.m2);
+        if (last_row && ov) gather9_slow(ref, r1, W, px, R.m0, R.m1, R.m2);
     }
     return R;
+}
+
+// second half of fetch_rows: the lower row from the lane 8 above (same block, next sample row)
+__device__ __forceinline__ void finish_rows(RefRows& R, int ov, bool last_row, int lane)
+{
+    const int src = ((lane + 8) & 63) << 2;
+    const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)R.l0);
+    const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)R.l1);
+    const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)R.l2);
+    if (!ov) { R.m0 = R.l0; R.m1 = R.l1; R.m2 = R.l2; }
+    else if (!last_row) { R.m0 = n0; R.m1 = n1; R.m2 = n2; }
 }
 
 // (a+b+c+d+2)>>2 / (a+b+1)>>1 / a, selected by the half-pel flags through operand
@@ -496,8 +513,8 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         }
         RefRows rf, rb;
         if (TYPE != 1) {
-            rf = fetch_rows(gptr(pd.ref_fwd) + plane_off, W, H, y, pxA, ayA, ohA, ovA, inA);
-            if (TYPE == 3) rb = fetch_rows(gptr(pd.ref_bwd) + plane_off, W, H, y, pxB, ayB, ohB, ovB, inB);
+            rf = fetch_rows(gptr(pd.ref_fwd) + plane_off, W, H, y, pxA, ayA, ohA, ovA, inA, hi3 == 7);
+            if (TYPE == 3) rb = fetch_rows(gptr(pd.ref_bwd) + plane_off, W, H, y, pxB, ayB, ohB, ovB, inB, hi3 == 7);
         }
 
         // ---- stage 1: coefficient rows -> LDS tile [r][b][c] ------------------------------
@@ -573,8 +590,10 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
 
         // ---- stage 4: prediction, add, clamp, store ------------------------------------------
         if (TYPE != 1) {
+            finish_rows(rf, ovA, hi3 == 7, lane);
             v2u pred = predict8(rf);
             if (TYPE == 3) {
+                finish_rows(rb, ovB, hi3 == 7, lane);
                 v2u pb = predict8(rb);
                 v2u pf = usef ? pred : pb;
                 pb = useb ? pb : pred;
