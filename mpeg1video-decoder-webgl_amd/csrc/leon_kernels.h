@@ -496,6 +496,16 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     const uint32_t out_voff = ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)x0) | (valid ? 0u : kOobBit);
     const uint32_t half_step = CHROMA ? 0u : 8u * (uint32_t)W;   // luma: next block row; chroma: next plane
     v4i cv_next = buf_load_v4i_s(buf_rsrc(pd.coef[CHROMA ? 1 : 0]), coef_voff, 0u);
+    RefRows rfh[2], rbh[2];
+    if (TYPE != 1) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int Rh = CHROMA ? Rt : 2 * Rt + h;
+            const uint32_t po = CHROMA ? (h == 0 ? ysz : ysz + (ysz >> 2)) : 0u;
+            rfh[h] = fetch_rows(gptr(pd.ref_fwd) + po, W, H, 8 * Rh + hi3, pxA, ayA, ohA, ovA, inA, hi3 == 7);
+            if (TYPE == 3) rbh[h] = fetch_rows(gptr(pd.ref_bwd) + po, W, H, 8 * Rh + hi3, pxB, ayB, ohB, ovB, inB, hi3 == 7);
+        }
+    }
 #pragma unroll
     for (int half = 0; half < 2; half++) {
         const int comp = CHROMA ? 1 + half : 0;
@@ -511,11 +521,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
                 (void*)pd.coef[CHROMA ? 2 : 0], 0, half == 0 ? 0x7fffffff : 0, 0x00020000);
             cv_next = buf_load_v4i_s(rs, coef_voff, 2u * half_step);
         }
-        RefRows rf, rb;
-        if (TYPE != 1) {
-            rf = fetch_rows(gptr(pd.ref_fwd) + plane_off, W, H, y, pxA, ayA, ohA, ovA, inA, hi3 == 7);
-            if (TYPE == 3) rb = fetch_rows(gptr(pd.ref_bwd) + plane_off, W, H, y, pxB, ayB, ohB, ovB, inB, hi3 == 7);
-        }
+        RefRows rf = rfh[half], rb = rbh[half];
 
         // ---- stage 1: coefficient rows -> LDS tile [r][b][c] ------------------------------
         *reinterpret_cast<v4i*>(lds_wr) = cv;
