@@ -135,10 +135,8 @@ void upload_tables(leon_decoder* d)
 {
     for (int c = 0; c < 8; c++)
         for (int i = 0; i < 8; i++) {
-            for (int q = 0; q < 32; q++) {
-                d->h_tables.qO[q][0][c][i] = (uint32_t)(q * d->qm[i * 8 + c]);
-                d->h_tables.qO[q][1][c][i] = (uint32_t)(q * d->qm[64 + i * 8 + c]);
-            }
+            d->h_tables.qmT[0][c][i] = d->qm[i * 8 + c];
+            d->h_tables.qmT[1][c][i] = d->qm[64 + i * 8 + c];
             d->h_tables.pmT[c][i] = kPremultiplier[i * 8 + c];
         }
 }

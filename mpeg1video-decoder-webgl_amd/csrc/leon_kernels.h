@@ -67,7 +67,7 @@ struct Geom {
 };
 
 struct Tables {                  // T6, per sequence
-    uint32_t qO[32][2][8][8];    // [quantiser_scale][0 intra | 1 non-intra][column c][row i] = q * Q[i][c]
+    uint8_t qmT[2][8][8];        // [0 intra | 1 non-intra][column c][row i] = Q[i][c]
     uint8_t pmT[8][8];           // premultiplier, [column c][row i]
 };
 
@@ -439,11 +439,20 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     const int Qb = g * 8 + b;
     const bool valid = Qb < bw;
     const int Qs = valid ? Qb : bw - 1;
+    const int c = hi3;
+    // everything that does not depend on the macroblock maps is requested first: the first
+    // coefficient rows and this lane's column of both quantiser matrices and of the premultiplier
+    // (the product quantiser_scale * matrix entry is formed in registers once the maps arrived;
+    // a table indexed by the scale would put a second dependent memory round trip here)
+    const int R0 = CHROMA ? Rt : 2 * Rt;
+    const uint32_t coef_voff = (2u * ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)(8 * Qld))) | (ld_ok ? 0u : kOobBit);
+    v4i cv_next = buf_load_v4i_s(buf_rsrc(pd.coef[CHROMA ? 1 : 0]), coef_voff, 0u);
+    const v2u mI = ldg<v2u>(T, (uint32_t)c * 8u), mN = ldg<v2u>(T, 64u + (uint32_t)c * 8u);
+    const v2u pm8 = ldg<v2u>(T, 128u + (uint32_t)c * 8u);
     const uint32_t mb = (uint32_t)(CHROMA ? Rt * G.mbw + Qs : Rt * G.mbw + (Qs >> 1));
     const int q = ldg<uint8_t>(gptr(pd.qscale), mb) & 31;
     const bool ia = ldg<uint8_t>(gptr(pd.intra), mb) != 0;   // I pictures honour the map too (COL_3)
     const int x0 = 8 * Qs;
-    const int c = hi3;
     bool nopred = false;
     // per reference: window column, half-pel flags, vertical offset, base selection
     int pxA = 0, ayA = 0, ohA = 0, ovA = 0, pxB = 0, ayB = 0, ohB = 0, ovB = 0;
@@ -478,10 +487,10 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             inB = pxB >= 0 && pxB + 7 + ohB <= W - 1;
         }
     }
-    const uint32_t qoff = (uint32_t)q * 512u + (ia ? 0u : 256u) + (uint32_t)c * 32u;
-    const v4u qoA = ldg<v4u>(T, qoff), qoB = ldg<v4u>(T, qoff + 16u);
-    const v2u pm8 = ldg<v2u>(T, (uint32_t)sizeof(T->qO) + (uint32_t)c * 8u);
-    const uint32_t qow[8] = {qoA.x, qoA.y, qoA.z, qoA.w, qoB.x, qoB.y, qoB.z, qoB.w};
+    const v2u msel = ia ? mI : mN;
+    uint32_t qow[8];                                  // quantiser_scale * Q[i][c], < 2^13
+#pragma unroll
+    for (int i = 0; i < 8; i++) qow[i] = __umul24((uint32_t)q, ((i < 4 ? msel.x : msel.y) >> (8 * (i & 3))) & 255u);
     int nim = ia ? 0 : -1;
     asm("" : "+v"(nim));                              // keep it a mask (v_and), not a select
     const bool dc_lane = c == 0 && ia;
@@ -491,11 +500,8 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     const v4i* const rp = reinterpret_cast<const v4i*>(lds + kLdsCoef + b * kLdsHandoffPitch + hi3 * 32);
 
     // per-lane offsets of the task's first half; the second half differs by a scalar
-    const int R0 = CHROMA ? Rt : 2 * Rt;
-    const uint32_t coef_voff = (2u * ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)(8 * Qld))) | (ld_ok ? 0u : kOobBit);
     const uint32_t out_voff = ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)x0) | (valid ? 0u : kOobBit);
     const uint32_t half_step = CHROMA ? 0u : 8u * (uint32_t)W;   // luma: next block row; chroma: next plane
-    v4i cv_next = buf_load_v4i_s(buf_rsrc(pd.coef[CHROMA ? 1 : 0]), coef_voff, 0u);
     RefRows rfh[2], rbh[2];
     if (TYPE != 1) {
 #pragma unroll
