@@ -277,7 +277,9 @@ __device__ __forceinline__ int dequant_any(int X, int qO, int pm, int nim, int l
     int x2 = (X << 1) + (sg & nim);
     int t = mul24_asm(x2, qO);
     int f = t >> 4;
-    f = (f - med3_asm(f, 0, 1)) | (sg & 1);
+    int z;
+    asm("v_med3_i32 %0, %1, 0, 1" : "=v"(z) : "v"(f));   // inline constants: no registers for 0 and 1
+    f = (f - z) | (sg & 1);
     f = med3_asm(f, lo2048, hi2047);
     return __mul24(f, pm);
 }
@@ -371,15 +373,15 @@ __device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, in
     return R;
 }
 
-// second half of fetch_rows: the lower row from the lane 8 above (same block, next sample row)
+// second half of fetch_rows: the lower row comes from the lane 8 above (same block, next sample
+// row) -- or from the lane itself when the vector has no vertical half-pel part
 __device__ __forceinline__ void finish_rows(RefRows& R, int ov, bool last_row, int lane)
 {
-    const int src = ((lane + 8) & 63) << 2;
+    const int src = (ov ? ((lane + 8) & 63) : lane) << 2;
     const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)R.l0);
     const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)R.l1);
     const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)R.l2);
-    if (!ov) { R.m0 = R.l0; R.m1 = R.l1; R.m2 = R.l2; }
-    else if (!last_row) { R.m0 = n0; R.m1 = n1; R.m2 = n2; }
+    if (!(last_row && ov)) { R.m0 = n0; R.m1 = n1; R.m2 = n2; }
 }
 
 // (a+b+c+d+2)>>2 / (a+b+1)>>1 / a, selected by the half-pel flags through operand
@@ -493,6 +495,10 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     for (int i = 0; i < 8; i++) qow[i] = __umul24((uint32_t)q, ((i < 4 ? msel.x : msel.y) >> (8 * (i & 3))) & 255u);
     int nim = ia ? 0 : -1;
     asm("" : "+v"(nim));                              // keep it a mask (v_and), not a select
+    // the clamp bounds live in two registers for the whole task (v_med3 takes no literals on
+    // gfx950, and the compiler would otherwise re-materialise them in front of every use)
+    int lo2048 = -2048, hi2047 = 2047;
+    asm("" : "+v"(lo2048), "+v"(hi2047));
     const bool dc_lane = c == 0 && ia;
     char* const lds_wr = lds + hi3 * 128 + lo3 * 16;
     const char* const lds_col = lds + b * 16 + c * 2;
@@ -552,7 +558,6 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             const int cols_live = 8 - (__builtin_clzll(colbits | 1ull) >> 3);
             // ---- stage 2: column pass ------------------------------------------------------
             const int dc = X[0];
-            const int lo2048 = -2048, hi2047 = 2047;
             int rows_live = 1;                            // wave-uniform: 1 + highest row with a non-zero
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -595,9 +600,13 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             if (cols_live > 4) w1 = rp[1];
             int Y[8] = {w0.x + 128, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};   // "+128" of (t+128)/256
             butterfly8_n(Y, cols_live, t);
-            // t/256 truncating == arithmetic shift after adding 255 to negative values
+            // t/256 truncating == arithmetic shift after adding 255 to negative values.  Without a
+            // prediction (I pictures) the difference between truncation and floor is invisible:
+            // it only exists for negative t, which the final clamp turns into 0 either way.
+            if (TYPE != 1) {
 #pragma unroll
-            for (int m = 0; m < 8; m++) t[m] += (t[m] >> 31) & 255;
+                for (int m = 0; m < 8; m++) t[m] += (t[m] >> 31) & 255;
+            }
         }
 
         // ---- stage 4: prediction, add, clamp, store ------------------------------------------
