@@ -200,6 +200,7 @@ def main():
     dec.timing_enable(False)
     recon = dec.timing_get(0)
     conv = dec.timing_get(1)
+    per_type = {n: dec.timing_get(k) for n, k in (("I", 2), ("P", 3), ("B", 4))}
 
     if world > 1:
         cdev = "cuda" if backend == "nccl" else "cpu"
@@ -239,7 +240,12 @@ def main():
                          "traffic": traffic, "traffic_source": traffic_src, "launches": recon["launches"],
                          "avg_launch_ms": recon["total_ms"] / max(1, recon["launches"]),
                          "algorithmic_bytes_per_launch": recon["algorithmic_bytes"] / max(1, recon["launches"]),
-                         "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None},
+                         "measured_copy_gbps": copy_gbps, "frac_of_measured_copy": achieved / copy_gbps if copy_gbps else None,
+                         # the motion-compensated launches reported separately
+                         "per_picture_type": {n: {"achieved": (t["algorithmic_bytes"] / (t["total_ms"] * 1e-3) / 1e9) if t["total_ms"] else None,
+                                                  "launches": t["launches"],
+                                                  "avg_launch_ms": t["total_ms"] / max(1, t["launches"])}
+                                              for n, t in per_type.items()}},
             "rgba_kernel": {"achieved_gbps": conv["algorithmic_bytes"] / (conv["total_ms"] * 1e-3) / 1e9 if conv["total_ms"] else None,
                             "launches": conv["launches"]},
             "stream_index_bytes": int(index["blob_bytes"]),

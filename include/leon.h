@@ -155,7 +155,8 @@ int leon_sync(leon_decoder* d);
 int leon_set_overlap_convert(leon_decoder* d, int32_t on);
 
 /* HIP-event timing of the kernels launched by this decoder (bench.py roofline).
- * kind: 0 = reconstruction kernel (dequant+IDCT+MC), 1 = colour conversion. */
+ * kind: 0 = reconstruction kernel (dequant+IDCT+MC), all picture types; 1 = colour conversion;
+ *       2 / 3 / 4 = the reconstruction launches of I / P / B pictures only. */
 int leon_timing_enable(leon_decoder* d, int32_t on);
 int leon_timing_reset(leon_decoder* d);
 int leon_timing_get(leon_decoder* d, int32_t kind, leon_kernel_stats* out);

@@ -53,6 +53,7 @@ const uint8_t kPremultiplier[64] = {
 struct TimedLaunch {
     hipEvent_t a, b;
     int kind;
+    int pic_type;      // reconstruction launches: LEON_PIC_I/P/B, else 0
     double bytes;
     uint64_t mbs;
 };
@@ -205,6 +206,7 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n)
         tl.a = get_event(d);
         tl.b = get_event(d);
         tl.kind = 0;
+        tl.pic_type = type;
         tl.mbs = (uint64_t)d->geom.mbw * d->geom.mbh * (uint64_t)n;
         tl.bytes = algo_bytes_per_mb(type) * (double)tl.mbs;
         HIP_TRY(hipEventRecord(tl.a, d->stream));
@@ -731,7 +733,8 @@ int leon_timing_get(leon_decoder* d, int32_t kind, leon_kernel_stats* out)
     if (d->conv_stream) HIP_TRY(hipStreamSynchronize(d->conv_stream));
     leon_kernel_stats s{};
     for (auto& t : d->timed) {
-        if (t.kind != kind) continue;
+        // kinds 2..4: the reconstruction launches of one picture type (I, P, B)
+        if (kind >= 2 ? (t.kind != 0 || t.pic_type != kind - 1) : t.kind != kind) continue;
         float ms = 0;
         HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
         s.launches++;
