@@ -1,0 +1,102 @@
+/*
+ * leon_vlc.h -- C ABI of the native bitstream front end (libleon_vlc.so; plain C++17, no GPU).
+ *
+ * the reference parses the stream with a bit-serial tree walk on one
+ * JavaScript thread (readCode decoders/jsv.js:1593-1599, getBits decoders/bitreader.js:443-540,
+ * decodeBlockGL :1338-1525) and uploads 6.27 MB of dense int16 planes per 1080p picture
+ * (:1237-1243).  This library replaces that layer with a table-driven multi-bit parser that
+ * decodes the slices of a picture on worker threads (slices are independently decodable after
+ * their start code) and emits the coefficients as SPARSE per-group lists -- what
+ * leon_submit_sparse() of include/leon.h consumes -- next to the same per-macroblock maps the
+ * reference uploads.  Same stream semantics as the JavaScript mirror of the reference parser
+ * (mpeg1video-decoder-webgl_amd/js/jsv_decoder.js), which is pinned to the reference by
+ * tests/golden/parser_*.json; B pictures are read too (ISO/IEC 11172-2).
+ *
+ * Sparse coefficient format ("group lists"):
+ *   A group is 8 horizontally adjacent 8x8 blocks (64x8 samples) of one plane -- the unit one
+ *   GPU wave reconstructs.  groups_y = ceil(coded_width/64) groups per luma block row,
+ *   groups_c = ceil(coded_width/128) per chroma block row.  Group ids:
+ *     luma   block row R (0 .. 2*mb_height-1), group g :  R*groups_y + g
+ *     Cb     block row R (0 .. mb_height-1)            :  n_y + R*groups_c + g
+ *     Cr                                               :  n_y + n_c + R*groups_c + g
+ *   with n_y = 2*mb_height*groups_y, n_c = mb_height*groups_c, n_groups = n_y + 2*n_c.
+ *   grp_off[n_groups+1] are prefix offsets into entries[]; the entries of a group are
+ *   contiguous, in no particular order.  One entry = one non-zero level:
+ *     bits  0..15  level (int16; intra DC in the 0..255 predictor domain, jsv.js:1346-1443)
+ *     bits 16..25  byte offset of the coefficient in the group's int16 tile [row r][block b][col c]
+ *                  = r*128 + b*16 + c*2   (r, c natural order inside the block; b = block in group)
+ */
+#ifndef LEON_VLC_H
+#define LEON_VLC_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum {
+    LEON_VLC_OK = 0,
+    LEON_VLC_END = 0,            /* leon_vlc_next_picture: end of stream */
+    LEON_VLC_PICTURE = 1,        /* leon_vlc_next_picture: *out is filled */
+    LEON_VLC_ERR_INVALID = -1,   /* bad argument */
+    LEON_VLC_ERR_STREAM = -2,    /* malformed stream (invalid code, coefficient index overflow ...) */
+    LEON_VLC_ERR_NOMEM = -3
+};
+
+typedef struct leon_vlc_stream leon_vlc_stream;
+
+typedef struct leon_vlc_info {
+    int32_t frame_width, frame_height;     /* sequence header (jsv.js:491-497) */
+    int32_t coded_width, coded_height;     /* mb_width<<4, mb_height<<4 (jsv.js:364-365) */
+    int32_t mb_width, mb_height;
+    int32_t groups_y, groups_c, n_groups;
+    int32_t has_alpha;                     /* 'a' flag of the container header (jsv.js:256-259) */
+    double  picture_rate;
+    double  duration;                      /* seconds, container header */
+    uint32_t keymap_count;                 /* START_MAP entries (jsv.js:264-268) */
+    uint32_t threads;                      /* worker threads in use (including the caller) */
+    uint8_t intra_qm[64], non_intra_qm[64];/* natural order; defaults when the stream has none */
+} leon_vlc_info;
+
+typedef struct leon_vlc_picture {
+    int32_t type;                 /* 1 I, 2 P, 3 B */
+    int32_t temporal_reference;
+    double  ts_ms;                /* GOP time code of the first picture after a GOP header, else 0 (jsv.js:471-489) */
+    int32_t new_sequence;         /* 1: a sequence header preceded this picture (matrices in leon_vlc_info may differ) */
+    int32_t n_groups;
+    uint32_t n_entries;
+    const uint32_t* grp_off;      /* [n_groups+1] */
+    const uint32_t* entries;      /* [n_entries] */
+    const uint8_t* qscale;        /* [mb_height*mb_width], persists across pictures (jsv.js:391-393) */
+    const uint8_t* intra;
+    const uint8_t* repadd;        /* P, B; else NULL */
+    const int16_t* mv_fwd;        /* P, B */
+    const int16_t* mv_bwd;        /* B */
+    const uint8_t* mb_dir;        /* B */
+    uint32_t n_slices;
+} leon_vlc_picture;
+
+const char* leon_vlc_last_error(void);
+
+/* Copies `n` bytes of a JSV stream (container header + key map, decoders/jsv.js:237-313) or of a
+ * raw MPEG-1 video elementary stream (starts with 00 00 01 B3).  threads <= 0: one per hardware
+ * thread, at most 16.  Reads up to the first sequence header so that leon_vlc_get_info is valid. */
+int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_stream** out);
+void leon_vlc_close(leon_vlc_stream* s);
+int leon_vlc_get_info(leon_vlc_stream* s, leon_vlc_info* out);
+
+/* = decodeFrame (decoders/jsv.js:426-469) without the reconstruction: parses up to and including
+ * the next picture.  The arrays of *out belong to the stream and stay valid until the next call. */
+int leon_vlc_next_picture(leon_vlc_stream* s, leon_vlc_picture* out);
+
+/* = jsv.prototype.seek (decoders/jsv.js:1618-1648): position on the key-map entry at or before
+ * `seconds`; decoding resumes at the next sequence header.  *byte_offset receives the offset. */
+int leon_vlc_seek(leon_vlc_stream* s, double seconds, uint64_t* byte_offset);
+
+/* sparse lists -> the dense int16 planes the reference uploads (planes are overwritten) */
+int leon_vlc_densify(const leon_vlc_info* info, const leon_vlc_picture* pic, int16_t* y, int16_t* cb, int16_t* cr);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,786 @@
+// leon_vlc.cpp -- native bitstream front end behind include/leon_vlc.h (no GPU code).
+//
+// Same stream semantics as js/jsv_decoder.js (the JavaScript mirror of the reference's parser,
+// decoders/jsv.js), restated for throughput:
+//   - every variable-length code is one table lookup on the next 6..16 bits
+//     (the reference walks a binary tree one bit at a time, jsv.js:1593-1599)
+//   - the slices of a picture are located by their start codes first and then decoded
+//     concurrently on a small thread pool: a slice carries its own predictors, quantiser scale and
+//     macroblock address (jsv.js:683-706), and writes only its own macroblocks
+//   - coefficients leave as sparse (group, tile offset, level) entries, bucketed per 64x8 group by
+//     a counting sort, instead of dense planes
+#include <atomic>
+#include <condition_variable>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <thread>
+#include <vector>
+
+#include "../../include/leon_vlc.h"
+
+namespace {
+
+thread_local char g_err[256] = "";
+int fail(int code, const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+    return code;
+}
+
+// ---- ISO/IEC 11172-2 Annex B tables as (value, code, length), expanded to flat lookups ----------
+
+struct Lookup {
+    std::vector<int32_t> t;      // (len << 16) | value; 0 = invalid
+    int max_len = 0;
+    void init(int ml) { max_len = ml; t.assign((size_t)1 << ml, 0); }
+    void add(int value, unsigned code, int len)
+    {
+        const int shift = max_len - len;
+        const int32_t packed = (len << 16) | (value & 0xffff);
+        for (unsigned i = 0; i < (1u << shift); i++) t[((size_t)code << shift) + i] = packed;
+    }
+};
+
+struct CL { unsigned code; int len; };
+
+const CL kMba[33] = {{0x1, 1}, {0x3, 3}, {0x2, 3}, {0x3, 4}, {0x2, 4}, {0x3, 5}, {0x2, 5}, {0x7, 7}, {0x6, 7}, {0xb, 8},
+    {0xa, 8}, {0x9, 8}, {0x8, 8}, {0x7, 8}, {0x6, 8}, {0x17, 10}, {0x16, 10}, {0x15, 10}, {0x14, 10}, {0x13, 10},
+    {0x12, 10}, {0x23, 11}, {0x22, 11}, {0x21, 11}, {0x20, 11}, {0x1f, 11}, {0x1e, 11}, {0x1d, 11}, {0x1c, 11},
+    {0x1b, 11}, {0x1a, 11}, {0x19, 11}, {0x18, 11}};
+const CL kCbp[64] = {{0x1, 9}, {0xb, 5}, {0x9, 5}, {0xd, 6}, {0xd, 4}, {0x17, 7}, {0x13, 7}, {0x1f, 8}, {0xc, 4}, {0x16, 7},
+    {0x12, 7}, {0x1e, 8}, {0x13, 5}, {0x1b, 8}, {0x17, 8}, {0x13, 8}, {0xb, 4}, {0x15, 7}, {0x11, 7}, {0x1d, 8},
+    {0x11, 5}, {0x19, 8}, {0x15, 8}, {0x11, 8}, {0xf, 6}, {0xf, 8}, {0xd, 8}, {0x3, 9}, {0xf, 5}, {0xb, 8},
+    {0x7, 8}, {0x7, 9}, {0xa, 4}, {0x14, 7}, {0x10, 7}, {0x1c, 8}, {0xe, 6}, {0xe, 8}, {0xc, 8}, {0x2, 9},
+    {0x10, 5}, {0x18, 8}, {0x14, 8}, {0x10, 8}, {0xe, 5}, {0xa, 8}, {0x6, 8}, {0x6, 9}, {0x12, 5}, {0x1a, 8},
+    {0x16, 8}, {0x12, 8}, {0xd, 5}, {0x9, 8}, {0x5, 8}, {0x5, 9}, {0xc, 5}, {0x8, 8}, {0x4, 8}, {0x4, 9},
+    {0x7, 3}, {0xa, 5}, {0x8, 5}, {0xc, 6}};
+const CL kMotion[17] = {{0x1, 1}, {0x1, 2}, {0x1, 3}, {0x1, 4}, {0x3, 6}, {0x5, 7}, {0x4, 7}, {0x3, 7}, {0xb, 9}, {0xa, 9},
+    {0x9, 9}, {0x11, 10}, {0x10, 10}, {0xf, 10}, {0xe, 10}, {0xd, 10}, {0xc, 10}};
+const CL kCoef[111] = {
+    {0x3, 2}, {0x4, 4}, {0x5, 5}, {0x6, 7}, {0x26, 8}, {0x21, 8}, {0xa, 10}, {0x1d, 12}, {0x18, 12}, {0x13, 12},
+    {0x10, 12}, {0x1a, 13}, {0x19, 13}, {0x18, 13}, {0x17, 13}, {0x1f, 14}, {0x1e, 14}, {0x1d, 14}, {0x1c, 14},
+    {0x1b, 14}, {0x1a, 14}, {0x19, 14}, {0x18, 14}, {0x17, 14}, {0x16, 14}, {0x15, 14}, {0x14, 14}, {0x13, 14},
+    {0x12, 14}, {0x11, 14}, {0x10, 14}, {0x18, 15}, {0x17, 15}, {0x16, 15}, {0x15, 15}, {0x14, 15}, {0x13, 15},
+    {0x12, 15}, {0x11, 15}, {0x10, 15},
+    {0x3, 3}, {0x6, 6}, {0x25, 8}, {0xc, 10}, {0x1b, 12}, {0x16, 13}, {0x15, 13}, {0x1f, 15}, {0x1e, 15}, {0x1d, 15},
+    {0x1c, 15}, {0x1b, 15}, {0x1a, 15}, {0x19, 15}, {0x13, 16}, {0x12, 16}, {0x11, 16}, {0x10, 16},
+    {0x5, 4}, {0x4, 7}, {0xb, 10}, {0x14, 12}, {0x14, 13},
+    {0x7, 5}, {0x24, 8}, {0x1c, 12}, {0x13, 13},
+    {0x6, 5}, {0xf, 10}, {0x12, 12},
+    {0x7, 6}, {0x9, 10}, {0x12, 13},
+    {0x5, 6}, {0x1e, 12}, {0x14, 16},
+    {0x4, 6}, {0x15, 12}, {0x7, 7}, {0x11, 12}, {0x5, 7}, {0x11, 13}, {0x27, 8}, {0x10, 13},
+    {0x23, 8}, {0x1a, 16}, {0x22, 8}, {0x19, 16}, {0x20, 8}, {0x18, 16}, {0xe, 10}, {0x17, 16}, {0xd, 10}, {0x16, 16},
+    {0x8, 10}, {0x15, 16},
+    {0x1f, 12}, {0x1a, 12}, {0x19, 12}, {0x17, 12}, {0x16, 12}, {0x1f, 13}, {0x1e, 13}, {0x1d, 13}, {0x1c, 13},
+    {0x1b, 13}, {0x1f, 16}, {0x1e, 16}, {0x1d, 16}, {0x1c, 16}, {0x1b, 16}};
+
+const uint8_t kZigZag[64] = {0, 1, 8, 16, 9, 2, 3, 10, 17, 24, 32, 25, 18, 11, 4, 5, 12, 19, 26, 33, 40, 48, 41, 34,
+    27, 20, 13, 6, 7, 14, 21, 28, 35, 42, 49, 56, 57, 50, 43, 36, 29, 22, 15, 23, 30, 37, 44, 51, 58, 59, 52, 45,
+    38, 31, 39, 46, 53, 60, 61, 54, 47, 55, 62, 63};
+const double kPictureRate[16] = {0, 23.976, 24, 25, 29.97, 30, 50, 59.94, 60, 15, 5, 10, 12, 15, 0, 0};   // jsv.js:1762-1765
+const uint8_t kDefaultIntra[64] = {
+    8, 16, 19, 22, 26, 27, 29, 34, 16, 16, 22, 24, 27, 29, 34, 37, 19, 22, 26, 27, 29, 34, 34, 38, 22, 22, 26, 27, 29, 34, 37, 40,
+    22, 26, 27, 29, 32, 35, 40, 48, 26, 27, 29, 32, 35, 40, 48, 58, 26, 27, 29, 34, 38, 46, 56, 69, 27, 29, 35, 38, 46, 56, 69, 83};
+
+struct Tables {
+    Lookup mba, mbtype[4], cbp, motion, dc_lum, dc_chr, coef;
+    Tables()
+    {
+        mba.init(11);
+        for (int i = 0; i < 33; i++) mba.add(i + 1, kMba[i].code, kMba[i].len);
+        mba.add(34, 0xf, 11);                                  // stuffing
+        mba.add(35, 0x8, 11);                                  // escape
+        // macroblock_type flags: 0x10 quant | 0x08 fwd | 0x04 bwd | 0x02 pattern | 0x01 intra
+        mbtype[1].init(2);
+        mbtype[1].add(0x01, 0x1, 1); mbtype[1].add(0x11, 0x1, 2);
+        mbtype[2].init(6);
+        const int p[7][3] = {{0x0a, 0x1, 1}, {0x02, 0x1, 2}, {0x08, 0x1, 3}, {0x01, 0x3, 5}, {0x1a, 0x2, 5}, {0x12, 0x1, 5}, {0x11, 0x1, 6}};
+        for (auto& e : p) mbtype[2].add(e[0], (unsigned)e[1], e[2]);
+        mbtype[3].init(6);
+        const int b[11][3] = {{0x0c, 0x2, 2}, {0x0e, 0x3, 2}, {0x04, 0x2, 3}, {0x06, 0x3, 3}, {0x08, 0x2, 4}, {0x0a, 0x3, 4},
+                              {0x01, 0x3, 5}, {0x1e, 0x2, 5}, {0x1a, 0x3, 6}, {0x16, 0x2, 6}, {0x11, 0x1, 6}};
+        for (auto& e : b) mbtype[3].add(e[0], (unsigned)e[1], e[2]);
+        cbp.init(9);
+        for (int i = 1; i < 64; i++) cbp.add(i, kCbp[i].code, kCbp[i].len);
+        motion.init(10);
+        for (int i = 0; i < 17; i++) motion.add(i, kMotion[i].code, kMotion[i].len);
+        dc_lum.init(7);
+        const int dl[9][2] = {{0x4, 3}, {0x0, 2}, {0x1, 2}, {0x5, 3}, {0x6, 3}, {0xe, 4}, {0x1e, 5}, {0x3e, 6}, {0x7e, 7}};
+        for (int i = 0; i < 9; i++) dc_lum.add(i, (unsigned)dl[i][0], dl[i][1]);
+        dc_chr.init(8);
+        const int dc[9][2] = {{0x0, 2}, {0x1, 2}, {0x2, 2}, {0x6, 3}, {0xe, 4}, {0x1e, 5}, {0x3e, 6}, {0x7e, 7}, {0xfe, 8}};
+        for (int i = 0; i < 9; i++) dc_chr.add(i, (unsigned)dc[i][0], dc[i][1]);
+        // dct coefficients without the sign bit; value = (run << 8) | level, 0xffff = escape,
+        // 0x0001 = '1' (run 0 level 1 in first position / with the next bit: '10' EOB, '11' 0/1)
+        coef.init(16);
+        int runs[111], levels[111], k = 0;
+        for (int l = 1; l <= 40; l++) { runs[k] = 0; levels[k++] = l; }
+        for (int l = 1; l <= 18; l++) { runs[k] = 1; levels[k++] = l; }
+        for (int l = 1; l <= 5; l++) { runs[k] = 2; levels[k++] = l; }
+        for (int l = 1; l <= 4; l++) { runs[k] = 3; levels[k++] = l; }
+        for (int r = 4; r <= 6; r++) for (int l = 1; l <= 3; l++) { runs[k] = r; levels[k++] = l; }
+        for (int r = 7; r <= 16; r++) for (int l = 1; l <= 2; l++) { runs[k] = r; levels[k++] = l; }
+        for (int r = 17; r <= 31; r++) { runs[k] = r; levels[k++] = 1; }
+        for (int i = 1; i < 111; i++) coef.add((runs[i] << 8) | levels[i], kCoef[i].code, kCoef[i].len);
+        coef.add(0x0001, 0x1, 1);
+        coef.add(0xffff, 0x1, 6);
+    }
+};
+const Tables& tables()
+{
+    static const Tables t;
+    return t;
+}
+
+// ---- bit reader over a zero-padded copy of the stream ------------------------------------------
+
+struct Bits {
+    const uint8_t* b = nullptr;
+    size_t nbytes = 0;           // real length (the buffer has 8 readable bytes more)
+    size_t pos = 0;              // in bits
+    bool bad = false;
+
+    uint32_t peek(int n) const   // n <= 24
+    {
+        const uint8_t* p = b + (pos >> 3);
+        const uint32_t v = ((uint32_t)p[0] << 24) | ((uint32_t)p[1] << 16) | ((uint32_t)p[2] << 8) | p[3];
+        return (v << (pos & 7)) >> (32 - n);
+    }
+    uint32_t get(int n)          // n <= 32
+    {
+        if (n == 0) return 0;
+        if (n > 24) { const uint32_t hi = get(n - 16); return (hi << 16) | get(16); }
+        if (pos + (size_t)n > nbytes * 8 + 32) { bad = true; return 0; }
+        const uint32_t v = peek(n);
+        pos += (size_t)n;
+        return v;
+    }
+    void skip(size_t n) { pos += n; }
+    int vlc(const Lookup& t)
+    {
+        if ((pos >> 3) >= nbytes) { bad = true; return 0; }
+        const int32_t e = t.t[peek(t.max_len)];
+        if (e == 0) { bad = true; return 0; }
+        pos += (size_t)(e >> 16);
+        return e & 0xffff;
+    }
+    // byte-aligned scan for 00 00 01 xx; returns xx with pos behind it, or -1 at the end
+    int next_start_code()
+    {
+        size_t i = (pos + 7) >> 3;
+        for (; i + 3 < nbytes; i++) {
+            if (b[i] == 0 && b[i + 1] == 0 && b[i + 2] == 1) { pos = (i + 4) << 3; return b[i + 3]; }
+        }
+        pos = nbytes * 8;
+        return -1;
+    }
+    bool next_bits_are_start_code() const      // decoders/jsv.js:1710-1760
+    {
+        const size_t i = (pos + 7) >> 3;
+        if (i + 2 >= nbytes) return true;
+        return b[i] == 0 && b[i + 1] == 0 && b[i + 2] == 1;
+    }
+};
+
+enum { START_PICTURE = 0x00, START_SLICE_FIRST = 0x01, START_SLICE_LAST = 0xAF, START_USER_DATA = 0xB2,
+       START_SEQUENCE_ES = 0xB3, START_SEQUENCE = 0xC3, START_EXTENSION = 0xB5, START_GOP = 0xB8, START_MAP = 0xC4 };
+
+struct SliceJob { int code; size_t bitpos; };
+
+}  // namespace
+
+struct leon_vlc_stream {
+    std::vector<uint8_t> data;
+    Bits r;
+    leon_vlc_info info{};
+    bool have_meta = false, sequence_started = false, skip_till_gop = true, ended = false, new_sequence = false;
+    bool raw_es = false;
+    std::vector<uint32_t> keymap;              // (byte offset, time code) pairs
+    double ts_pending = 0;
+    int temporal_reference = 0;
+
+    // per-picture state (decoders/jsv.js:583-676)
+    int type = 0;
+    int full_pel_fwd = 0, fwd_rsize = 0, fwd_f = 1, full_pel_bwd = 0, bwd_rsize = 0, bwd_f = 1;
+    int mbw = 0, mbh = 0, mbsize = 0, gy = 0, gc = 0, n_y = 0, n_c = 0;
+    std::vector<uint8_t> qscale, intra, repadd, mb_dir;
+    std::vector<int16_t> mv_fwd, mv_bwd;
+    std::vector<uint32_t> grp_off, entries, cursor;
+
+    // thread pool
+    int n_threads = 1;
+    std::vector<std::thread> workers;
+    std::mutex mu;
+    std::condition_variable cv_work, cv_done;
+    uint64_t generation = 0;
+    bool quit = false;
+    int busy = 0;
+    std::vector<SliceJob> jobs;
+    std::atomic<size_t> next_job{0};
+    std::vector<std::vector<uint64_t>> items;  // per thread: (group << 32) | entry
+    std::atomic<int> slice_error{0};
+    char slice_err_text[160] = "";
+    std::mutex err_mu;
+};
+
+namespace {
+
+struct SliceCtx {
+    leon_vlc_stream* s;
+    Bits r;
+    std::vector<uint64_t>* out;
+    int mb_addr = 0, mb_row = 0, mb_col = 0;
+    bool slice_begin = true;
+    int fw_h = 0, fw_v = 0, fw_h_prev = 0, fw_v_prev = 0, bw_h = 0, bw_v = 0, bw_h_prev = 0, bw_v_prev = 0, prev_dir = 0;
+    int dc_y = 128, dc_cr = 128, dc_cb = 128, qs = 0;
+    int mb_intra = 0, mot_fw = 0, mot_bw = 0;
+    const char* err = nullptr;
+};
+
+int motion_component(SliceCtx& c, int prev, int rsize, int f)
+{
+    Bits& r = c.r;
+    int code = r.vlc(tables().motion), d;
+    if (code != 0 && r.get(1)) code = -code;
+    if (code != 0 && f != 1) {
+        d = (((code < 0 ? -code : code) - 1) << rsize) + (int)r.get(rsize) + 1;
+        if (code < 0) d = -d;
+    } else d = code;
+    prev += d;
+    if (prev > (f << 4) - 1) prev -= f << 5;
+    else if (prev < -(f << 4)) prev += f << 5;
+    return prev;
+}
+
+// decoders/jsv.js:831-893 (+ backward vectors)
+void decode_motion_vectors(SliceCtx& c)
+{
+    leon_vlc_stream* s = c.s;
+    if (c.mot_fw) {
+        c.fw_h_prev = motion_component(c, c.fw_h_prev, s->fwd_rsize, s->fwd_f);
+        c.fw_h = s->full_pel_fwd ? c.fw_h_prev * 2 : c.fw_h_prev;
+        c.fw_v_prev = motion_component(c, c.fw_v_prev, s->fwd_rsize, s->fwd_f);
+        c.fw_v = s->full_pel_fwd ? c.fw_v_prev * 2 : c.fw_v_prev;
+    } else if (s->type == 2) {
+        c.fw_h = c.fw_h_prev = 0;
+        c.fw_v = c.fw_v_prev = 0;
+    }
+    if (c.mot_bw) {
+        c.bw_h_prev = motion_component(c, c.bw_h_prev, s->bwd_rsize, s->bwd_f);
+        c.bw_h = s->full_pel_bwd ? c.bw_h_prev * 2 : c.bw_h_prev;
+        c.bw_v_prev = motion_component(c, c.bw_v_prev, s->bwd_rsize, s->bwd_f);
+        c.bw_v = s->full_pel_bwd ? c.bw_v_prev * 2 : c.bw_v_prev;
+    }
+}
+
+// decoders/jsv.js:1338-1525 (decodeBlockGL): raw levels, emitted as sparse entries
+bool decode_block(SliceCtx& c, int block)
+{
+    leon_vlc_stream* s = c.s;
+    Bits& r = c.r;
+    const Tables& T = tables();
+    uint32_t gid, bq;
+    if (block < 4) {
+        const int rb = c.mb_row * 2 + (block >> 1), qb = c.mb_col * 2 + (block & 1);
+        gid = (uint32_t)(rb * s->gy + (qb >> 3));
+        bq = (uint32_t)(qb & 7);
+    } else {
+        gid = (uint32_t)(s->n_y + (block == 5 ? s->n_c : 0) + c.mb_row * s->gc + (c.mb_col >> 3));
+        bq = (uint32_t)(c.mb_col & 7);
+    }
+    const uint64_t ghi = (uint64_t)gid << 32;
+    const uint32_t boff = (bq * 16u) << 16;
+    int n = 0;
+    if (c.mb_intra) {
+        int predictor, size;
+        if (block < 4) { predictor = c.dc_y; size = r.vlc(T.dc_lum); }
+        else { predictor = block == 4 ? c.dc_cr : c.dc_cb; size = r.vlc(T.dc_chr); }
+        int dc = predictor;
+        if (size > 0) {
+            const int differential = (int)r.get(size);
+            dc = (differential & (1 << (size - 1))) ? predictor + differential
+                                                    : predictor + ((int)(0xffffffffu << size) | (differential + 1));
+        }
+        if (block < 4) c.dc_y = dc; else if (block == 4) c.dc_cr = dc; else c.dc_cb = dc;
+        if ((int16_t)dc != 0) c.out->push_back(ghi | boff | (uint16_t)(int16_t)dc);
+        n = 1;
+    }
+    for (;;) {
+        int run, level;
+        const int coeff = r.vlc(T.coef);
+        if (r.bad) { c.err = "invalid coefficient code"; return false; }
+        if (coeff == 0x0001 && n > 0 && r.get(1) == 0) break;          // '10' = end of block
+        if (coeff == 0xffff) {
+            run = (int)r.get(6);
+            level = (int)r.get(8);
+            if (level == 0) level = (int)r.get(8);
+            else if (level == 128) level = (int)r.get(8) - 256;
+            else if (level > 128) level -= 256;
+        } else {
+            run = coeff >> 8;
+            level = coeff & 0xff;
+            if (r.get(1)) level = -level;
+        }
+        n += run;
+        if (n > 63) { c.err = "coefficient index overflow"; return false; }
+        const uint32_t z = kZigZag[n++];
+        if (level != 0)
+            c.out->push_back(ghi | boff | (((z >> 3) * 128u + (z & 7u) * 2u) << 16) | (uint16_t)(int16_t)level);
+    }
+    return !r.bad;
+}
+
+// decoders/jsv.js:725-828 (+ B pictures).  1 = macroblock read, 0 = error (c.err), 2 = the
+// reference's silent return for an address past the picture (the slice loop goes on)
+int decode_macroblock(SliceCtx& c)
+{
+    leon_vlc_stream* s = c.s;
+    Bits& r = c.r;
+    const Tables& T = tables();
+    const int type = s->type;
+    int increment = 0, t = r.vlc(T.mba);
+    while (t == 34 && !r.bad) t = r.vlc(T.mba);
+    while (t == 35 && !r.bad) { increment += 33; t = r.vlc(T.mba); }
+    if (r.bad) { c.err = "invalid macroblock address increment"; return 0; }
+    increment += t;
+    if (c.slice_begin) {
+        c.slice_begin = false;
+        c.mb_addr += increment;
+    } else {
+        if (c.mb_addr + increment >= s->mbsize) return 2;
+        if (increment > 1) {
+            c.dc_y = c.dc_cr = c.dc_cb = 128;
+            if (type == 2) { c.fw_h = c.fw_h_prev = 0; c.fw_v = c.fw_v_prev = 0; }
+        }
+        while (increment > 1) {                                    // skipped macroblocks
+            const int a = ++c.mb_addr;
+            s->mv_fwd[2 * a] = (int16_t)c.fw_h;
+            s->mv_fwd[2 * a + 1] = (int16_t)c.fw_v;
+            if (type == 3) {
+                s->mv_bwd[2 * a] = (int16_t)c.bw_h;
+                s->mv_bwd[2 * a + 1] = (int16_t)c.bw_v;
+                s->mb_dir[a] = (uint8_t)c.prev_dir;
+            }
+            increment--;
+        }
+        c.mb_addr++;
+    }
+    const int mb = c.mb_addr;
+    if (mb < 0 || mb >= s->mbsize) { c.err = "macroblock address outside the picture"; return 0; }
+    c.mb_row = mb / s->mbw;
+    c.mb_col = mb % s->mbw;
+    const int mb_type = r.vlc(T.mbtype[type]);
+    if (r.bad) { c.err = "invalid macroblock type"; return 0; }
+    c.mb_intra = mb_type & 0x01;
+    c.mot_fw = mb_type & 0x08;
+    c.mot_bw = mb_type & 0x04;
+    if (mb_type & 0x10) c.qs = (int)r.get(5);
+    s->qscale[mb] = (uint8_t)c.qs;
+    s->intra[mb] = c.mb_intra ? 255 : 0;
+    if (c.mb_intra) {
+        c.fw_h = c.fw_h_prev = 0; c.fw_v = c.fw_v_prev = 0;
+        c.bw_h = c.bw_h_prev = 0; c.bw_v = c.bw_v_prev = 0;
+        c.prev_dir = 0;
+        if (type != 1) s->repadd[mb] = 255;                        // jsv.js:1502-1505
+    } else {
+        c.dc_y = c.dc_cr = c.dc_cb = 128;
+        decode_motion_vectors(c);
+        if (r.bad) { c.err = "invalid motion code"; return 0; }
+        s->mv_fwd[2 * mb] = (int16_t)c.fw_h;
+        s->mv_fwd[2 * mb + 1] = (int16_t)c.fw_v;
+        if (type == 3) {
+            s->mv_bwd[2 * mb] = (int16_t)c.bw_h;
+            s->mv_bwd[2 * mb + 1] = (int16_t)c.bw_v;
+            c.prev_dir = (c.mot_fw ? 1 : 0) | (c.mot_bw ? 2 : 0);
+            s->mb_dir[mb] = (uint8_t)c.prev_dir;
+        }
+    }
+    int cbp = 0;
+    if (mb_type & 0x02) { cbp = r.vlc(T.cbp); if (r.bad) { c.err = "invalid coded block pattern"; return 0; } }
+    else if (c.mb_intra) cbp = 0x3f;
+    for (int block = 0, mask = 0x20; block < 6; block++, mask >>= 1)
+        if (cbp & mask) { if (!decode_block(c, block)) return 0; }
+    return 1;
+}
+
+// decoders/jsv.js:683-706
+void decode_slice(leon_vlc_stream* s, const SliceJob& job, std::vector<uint64_t>* out)
+{
+    SliceCtx c;
+    c.s = s;
+    c.r = s->r;
+    c.r.pos = job.bitpos;
+    c.r.bad = false;
+    c.out = out;
+    c.mb_addr = (job.code - 1) * s->mbw - 1;
+    c.qs = (int)c.r.get(5);
+    while (c.r.get(1) && !c.r.bad) c.r.skip(8);
+    do {
+        if (decode_macroblock(c) == 0) break;
+    } while (!c.r.next_bits_are_start_code() && !c.r.bad);
+    if (c.r.bad && !c.err) c.err = "bitstream ends inside a slice";
+    if (c.err) {
+        std::lock_guard<std::mutex> lk(s->err_mu);
+        if (!s->slice_error.exchange(1))
+            snprintf(s->slice_err_text, sizeof(s->slice_err_text), "slice %d: %s near byte %zu", job.code, c.err, c.r.pos >> 3);
+    }
+}
+
+void run_jobs(leon_vlc_stream* s, int tid)
+{
+    for (;;) {
+        const size_t j = s->next_job.fetch_add(1);
+        if (j >= s->jobs.size()) break;
+        decode_slice(s, s->jobs[j], &s->items[(size_t)tid]);
+    }
+}
+
+void worker_main(leon_vlc_stream* s, int tid)
+{
+    uint64_t seen = 0;
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv_work.wait(lk, [&] { return s->quit || s->generation != seen; });
+            if (s->quit) return;
+            seen = s->generation;
+        }
+        run_jobs(s, tid);
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            if (--s->busy == 0) s->cv_done.notify_one();
+        }
+    }
+}
+
+// ---- headers ------------------------------------------------------------------------------------
+
+void init_buffers(leon_vlc_stream* s)        // decoders/jsv.js:355-423
+{
+    leon_vlc_info& I = s->info;
+    I.mb_width = (I.frame_width + 15) >> 4;
+    I.mb_height = (I.frame_height + 15) >> 4;
+    I.coded_width = I.mb_width << 4;
+    I.coded_height = I.mb_height << 4;
+    s->mbw = I.mb_width;
+    s->mbh = I.mb_height;
+    s->mbsize = s->mbw * s->mbh;
+    s->gy = (2 * s->mbw + 7) >> 3;
+    s->gc = (s->mbw + 7) >> 3;
+    s->n_y = 2 * s->mbh * s->gy;
+    s->n_c = s->mbh * s->gc;
+    I.groups_y = s->gy;
+    I.groups_c = s->gc;
+    I.n_groups = s->n_y + 2 * s->n_c;
+    s->qscale.assign((size_t)s->mbsize, 0);
+    s->intra.assign((size_t)s->mbsize, 0);
+    s->sequence_started = true;
+}
+
+bool decode_sequence_header(leon_vlc_stream* s)      // decoders/jsv.js:491-561
+{
+    Bits& r = s->r;
+    leon_vlc_info& I = s->info;
+    const int fw = (int)r.get(12), fh = (int)r.get(12);
+    r.skip(4);
+    const double rate = kPictureRate[r.get(4)];
+    r.skip(18 + 1);
+    r.get(10);
+    r.skip(1);
+    uint8_t intra[64], non[64];
+    memcpy(intra, kDefaultIntra, 64);
+    memset(non, 16, 64);
+    if (r.get(1)) for (int i = 0; i < 64; i++) intra[kZigZag[i]] = (uint8_t)r.get(8);
+    if (r.get(1)) for (int i = 0; i < 64; i++) non[kZigZag[i]] = (uint8_t)r.get(8);
+    if (r.bad || fw <= 0 || fh <= 0) return false;
+    if (!s->sequence_started) {
+        I.frame_width = fw;
+        I.frame_height = fh;
+        I.picture_rate = rate;
+        init_buffers(s);
+    }
+    memcpy(I.intra_qm, intra, 64);
+    memcpy(I.non_intra_qm, non, 64);
+    s->new_sequence = true;
+    return true;
+}
+
+void decode_gop_header(leon_vlc_stream* s)           // decoders/jsv.js:471-489
+{
+    Bits& r = s->r;
+    r.skip(1);
+    const int h = (int)r.get(5), m = (int)r.get(6);
+    r.skip(1);
+    const int sec = (int)r.get(6), f = (int)r.get(6);
+    const double rate = s->info.picture_rate > 0 ? s->info.picture_rate : 25.0;
+    s->ts_pending = ((h * 60 + m) * 60 + sec + (f + 1) / rate) * 1000.0;
+}
+
+// decoders/jsv.js:583-676 (+ B pictures).  1 = picture decoded, 0 = not a picture we read, <0 error
+int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
+{
+    Bits& r = s->r;
+    s->temporal_reference = (int)r.get(10);
+    const int type = (int)r.get(3);
+    r.skip(16);
+    if (type <= 0 || type > 3) return 0;
+    s->type = type;
+    s->mv_fwd.assign((size_t)s->mbsize * 2, 0);
+    if (type != 1) {
+        s->repadd.assign((size_t)s->mbsize, 0);
+        s->full_pel_fwd = (int)r.get(1);
+        const int fcode = (int)r.get(3);
+        if (fcode == 0) return 0;
+        s->fwd_rsize = fcode - 1;
+        s->fwd_f = 1 << s->fwd_rsize;
+    }
+    if (type == 3) {
+        s->mv_bwd.assign((size_t)s->mbsize * 2, 0);
+        s->mb_dir.assign((size_t)s->mbsize, 0);
+        s->full_pel_bwd = (int)r.get(1);
+        const int bcode = (int)r.get(3);
+        if (bcode == 0) return 0;
+        s->bwd_rsize = bcode - 1;
+        s->bwd_f = 1 << s->bwd_rsize;
+    }
+    // locate the slices; the picture ends at the first start code that is not a slice
+    int code;
+    do { code = r.next_start_code(); } while (code == START_EXTENSION || code == START_USER_DATA);
+    s->jobs.clear();
+    while (code >= START_SLICE_FIRST && code <= START_SLICE_LAST) {
+        s->jobs.push_back(SliceJob{code, r.pos});
+        code = r.next_start_code();
+    }
+    if (code >= 0) r.pos -= 32;                                    // rewind(32)
+
+    for (auto& v : s->items) v.clear();
+    s->next_job.store(0);
+    s->slice_error.store(0);
+    const int helpers = (int)s->workers.size();
+    if (helpers > 0 && s->jobs.size() > 1) {
+        {
+            std::lock_guard<std::mutex> lk(s->mu);
+            s->busy = helpers;
+            s->generation++;
+        }
+        s->cv_work.notify_all();
+        run_jobs(s, 0);
+        std::unique_lock<std::mutex> lk(s->mu);
+        s->cv_done.wait(lk, [&] { return s->busy == 0; });
+    } else {
+        run_jobs(s, 0);
+    }
+    if (s->slice_error.load()) return fail(LEON_VLC_ERR_STREAM, "%s", s->slice_err_text);
+
+    // counting sort of the (group, entry) items into per-group runs
+    const size_t ng = (size_t)s->info.n_groups;
+    s->grp_off.assign(ng + 1, 0);
+    size_t total = 0;
+    for (auto& v : s->items) {
+        total += v.size();
+        for (uint64_t it : v) {
+            const uint32_t g = (uint32_t)(it >> 32);
+            if (g < ng) s->grp_off[g + 1]++;
+        }
+    }
+    for (size_t g = 0; g < ng; g++) s->grp_off[g + 1] += s->grp_off[g];
+    s->entries.resize(s->grp_off[ng]);
+    s->cursor.assign(s->grp_off.begin(), s->grp_off.end() - 1);
+    for (auto& v : s->items)
+        for (uint64_t it : v) {
+            const uint32_t g = (uint32_t)(it >> 32);
+            if (g < ng) s->entries[s->cursor[g]++] = (uint32_t)it;
+        }
+    (void)total;
+
+    out->type = type;
+    out->temporal_reference = s->temporal_reference;
+    out->ts_ms = s->ts_pending;
+    s->ts_pending = 0;
+    out->new_sequence = s->new_sequence ? 1 : 0;
+    s->new_sequence = false;
+    out->n_groups = s->info.n_groups;
+    out->n_entries = (uint32_t)s->entries.size();
+    out->grp_off = s->grp_off.data();
+    out->entries = s->entries.data();
+    out->qscale = s->qscale.data();
+    out->intra = s->intra.data();
+    out->repadd = type != 1 ? s->repadd.data() : nullptr;
+    out->mv_fwd = type != 1 ? s->mv_fwd.data() : nullptr;
+    out->mv_bwd = type == 3 ? s->mv_bwd.data() : nullptr;
+    out->mb_dir = type == 3 ? s->mb_dir.data() : nullptr;
+    out->n_slices = (uint32_t)s->jobs.size();
+    return 1;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* leon_vlc_last_error(void) { return g_err; }
+
+int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_stream** out)
+{
+    if (!data || !out || n < 12) return fail(LEON_VLC_ERR_INVALID, "null or too short stream");
+    leon_vlc_stream* s = new (std::nothrow) leon_vlc_stream();
+    if (!s) return fail(LEON_VLC_ERR_NOMEM, "out of memory");
+    s->data.assign(data, data + n);
+    s->data.resize(n + 8, 0);
+    s->r.b = s->data.data();
+    s->r.nbytes = n;
+    s->r.pos = 0;
+    (void)tables();
+    Bits& r = s->r;
+    s->raw_es = data[0] == 0 && data[1] == 0 && data[2] == 1 && data[3] == START_SEQUENCE_ES;
+    if (!s->raw_es) {
+        // container header: decoders/jsv.js:237-313
+        r.skip(16);
+        r.get(16);
+        r.get(16);
+        double d = r.get(16) / 100.0;
+        if (d == 0) { s->info.has_alpha = (int)r.get(1); d = r.get(23) / 100.0; }
+        s->info.duration = d;
+        const size_t i = r.pos >> 3;
+        if (i + 12 <= n && s->data[i] == 0 && s->data[i + 1] == 0 && s->data[i + 2] == 1 && s->data[i + 3] == START_MAP) {
+            r.skip(32);
+            const uint32_t count = r.get(32);
+            if ((size_t)count * 8 > n) { delete s; return fail(LEON_VLC_ERR_STREAM, "key map larger than the stream"); }
+            s->keymap.resize((size_t)count * 2);
+            for (uint32_t k = 0; k < count; k++) { s->keymap[2 * k] = r.get(32); s->keymap[2 * k + 1] = r.get(32); }
+            s->info.keymap_count = count;
+        }
+    }
+    s->have_meta = true;
+    // read ahead to the first sequence header so that the geometry is known
+    const size_t resume = r.pos;
+    bool found = false;
+    for (;;) {
+        const int code = r.next_start_code();
+        if (code < 0) break;
+        if (code == START_SEQUENCE || (s->raw_es && code == START_SEQUENCE_ES)) {
+            if (!decode_sequence_header(s)) { delete s; return fail(LEON_VLC_ERR_STREAM, "bad sequence header"); }
+            found = true;
+            break;
+        }
+    }
+    if (!found) { delete s; return fail(LEON_VLC_ERR_STREAM, "no sequence header in the stream"); }
+    r.pos = resume;
+    s->new_sequence = false;
+
+    int nt = threads;
+    if (nt <= 0) { nt = (int)std::thread::hardware_concurrency(); if (nt < 1) nt = 1; if (nt > 16) nt = 16; }
+    if (nt > 64) nt = 64;
+    s->n_threads = nt;
+    s->info.threads = (uint32_t)nt;
+    s->items.resize((size_t)nt);
+    for (int t = 1; t < nt; t++) s->workers.emplace_back(worker_main, s, t);
+    *out = s;
+    return LEON_VLC_OK;
+}
+
+void leon_vlc_close(leon_vlc_stream* s)
+{
+    if (!s) return;
+    {
+        std::lock_guard<std::mutex> lk(s->mu);
+        s->quit = true;
+    }
+    s->cv_work.notify_all();
+    for (auto& t : s->workers) t.join();
+    delete s;
+}
+
+int leon_vlc_get_info(leon_vlc_stream* s, leon_vlc_info* out)
+{
+    if (!s || !out) return fail(LEON_VLC_ERR_INVALID, "null argument");
+    *out = s->info;
+    return LEON_VLC_OK;
+}
+
+int leon_vlc_next_picture(leon_vlc_stream* s, leon_vlc_picture* out)
+{
+    if (!s || !out) return fail(LEON_VLC_ERR_INVALID, "null argument");
+    if (s->ended) return LEON_VLC_END;
+    Bits& r = s->r;
+    for (;;) {                                                      // decoders/jsv.js:426-469
+        const int code = r.next_start_code();
+        if (code < 0) { s->ended = true; return LEON_VLC_END; }
+        if (code == START_SEQUENCE || (s->raw_es && code == START_SEQUENCE_ES)) {
+            if (!decode_sequence_header(s)) return fail(LEON_VLC_ERR_STREAM, "bad sequence header near byte %zu", r.pos >> 3);
+            s->skip_till_gop = false;
+            continue;
+        }
+        if (s->skip_till_gop) continue;
+        if (code == START_GOP) { decode_gop_header(s); continue; }
+        if (code == START_PICTURE && s->sequence_started) {
+            const int rc = decode_picture(s, out);
+            if (rc != 0) return rc;
+        }
+    }
+}
+
+int leon_vlc_seek(leon_vlc_stream* s, double seconds, uint64_t* byte_offset)
+{
+    if (!s) return fail(LEON_VLC_ERR_INVALID, "null argument");
+    uint64_t offset = 0;
+    const uint32_t count = s->info.keymap_count;
+    if (count) {
+        const double rate = s->info.picture_rate > 0 ? s->info.picture_rate : 25.0;
+        auto key_time = [&](uint32_t g) {                           // decoders/jsv.js:315-325
+            const uint32_t tc = s->keymap[2 * g + 1];
+            const int hour = (tc >> 26) & 31, minute = (tc >> 20) & 63, second = (tc >> 13) & 63, frame = (tc >> 7) & 63;
+            return (hour * 60 + minute) * 60 + second + (frame + 1) / rate;
+        };
+        const double dur = s->info.duration > 0 ? s->info.duration : 1.0;
+        double gf = (double)count * seconds / dur;
+        if (gf < 0) gf = 0;
+        uint32_t g = (uint32_t)gf;
+        if (g > count - 1) g = count - 1;
+        while (g > 0 && key_time(g) > seconds + 1e-9) g--;
+        while (g + 1 < count && key_time(g + 1) <= seconds + 1e-9) g++;
+        offset = s->keymap[2 * g];
+    }
+    if (offset > s->r.nbytes) return fail(LEON_VLC_ERR_STREAM, "key map entry beyond the stream");
+    s->r.pos = (size_t)offset * 8;
+    s->ended = false;
+    s->skip_till_gop = true;
+    if (byte_offset) *byte_offset = offset;
+    return LEON_VLC_OK;
+}
+
+int leon_vlc_densify(const leon_vlc_info* I, const leon_vlc_picture* p, int16_t* y, int16_t* cb, int16_t* cr)
+{
+    if (!I || !p || !y || !cb || !cr) return fail(LEON_VLC_ERR_INVALID, "null argument");
+    const int cw = I->coded_width, ch = I->coded_height, hw = cw >> 1;
+    memset(y, 0, sizeof(int16_t) * (size_t)cw * ch);
+    memset(cb, 0, sizeof(int16_t) * (size_t)(cw >> 1) * (ch >> 1));
+    memset(cr, 0, sizeof(int16_t) * (size_t)(cw >> 1) * (ch >> 1));
+    const int n_y = 2 * I->mb_height * I->groups_y, n_c = I->mb_height * I->groups_c;
+    for (int g = 0; g < p->n_groups; g++) {
+        int16_t* plane;
+        int stride, R, gg, bw;
+        if (g < n_y) { plane = y; stride = cw; R = g / I->groups_y; gg = g % I->groups_y; bw = cw >> 3; }
+        else {
+            const int k = (g - n_y) % n_c;
+            plane = g - n_y < n_c ? cb : cr;
+            stride = hw; R = k / I->groups_c; gg = k % I->groups_c; bw = hw >> 3;
+        }
+        for (uint32_t e = p->grp_off[g]; e < p->grp_off[g + 1]; e++) {
+            const uint32_t v = p->entries[e], off = (v >> 16) & 1023u;
+            const int r = (int)(off >> 7), b = (int)((off >> 4) & 7), c = (int)((off >> 1) & 7);
+            const int q = gg * 8 + b;
+            if (q >= bw) return fail(LEON_VLC_ERR_INVALID, "entry outside the plane");
+            plane[(size_t)(R * 8 + r) * stride + q * 8 + c] = (int16_t)(v & 0xffffu);
+        }
+    }
+    return LEON_VLC_OK;
+}
+
+}  // extern "C"

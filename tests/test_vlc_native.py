@@ -1,0 +1,179 @@
+"""CPU: the native bitstream front end (libleon_vlc.so, include/leon_vlc.h) against
+(a) the boundary tensors recorded from the UNMODIFIED reference parser (tests/golden/parser_*.json,
+    made by tools/make_golden.js -- the reference drops B pictures, so those are covered by (b)),
+(b) the product's JavaScript mirror of that parser under Node, picture by picture, B included,
+(c) its own invariants: thread-count independence, sparse <-> dense round trip, key-map seek,
+    and no crash on damaged input."""
+import ctypes
+import hashlib
+import json
+import os
+import shutil
+import subprocess
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, load_golden
+
+import leon_vlc_ctypes as V
+
+STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
+NAMES = ["tiny_ip_32x32", "leon_synth_352x240", "ibbp_96x64"]
+sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def read(name):
+    with open(os.path.join(STREAMS, name + ".jsv"), "rb") as f:
+        return f.read()
+
+
+def all_pictures(data, threads=0, dense=True):
+    st = V.Stream(data, threads=threads)
+    out = []
+    while True:
+        p = st.next_picture(dense=dense)
+        if p is None:
+            break
+        out.append(p)
+    return st, out
+
+
+def test_library_exports_every_declared_symbol():
+    lib = V.load()
+    text = open(os.path.join(ROOT, "include", "leon_vlc.h")).read()
+    for s in V.SYMBOLS:
+        assert s + "(" in text, s
+        assert getattr(lib, s) is not None
+
+
+def _ref_uploads(pic):
+    ups = [u for u in pic["uploads"] if "unit" in u]
+    coef = [u["sha256"] for u in ups if u["unit"] == 0]
+    unit2 = [u for u in ups if u["unit"] == 2]
+    d = {"coef": coef, "qscale": unit2[0]["sha256"], "intra": [u for u in ups if u["unit"] == 4][0]["sha256"]}
+    if pic["type"] == 2:
+        d["repadd"] = unit2[1]["sha256"]
+        d["mv"] = [u for u in ups if u["unit"] == 3][0]["sha256"]
+    return d
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_tensors_equal_reference_parser(name):
+    st, pics = all_pictures(read(name))
+    ref = load_golden("parser_%s.json" % name)
+    assert (st.info.mb_width, st.info.mb_height, st.info.coded_width) == (ref["mbWidth"], ref["mbHeight"], ref["codedWidth"])
+    mine = [p for p in pics if p["type"] != 3]
+    assert len(mine) == len(ref["pictures"]) > 0
+    for i, (p, r) in enumerate(zip(mine, ref["pictures"])):
+        assert p["type"] == r["type"], i
+        u = _ref_uploads(r)
+        assert [sha(p["coef_y"]), sha(p["coef_cb"]), sha(p["coef_cr"])] == u["coef"], "coefficients of picture %d" % i
+        if name != "ibbp_96x64":      # see tests/test_js_parser.py: stale map entries differ once B pictures are read
+            assert sha(p["qscale"]) == u["qscale"] and sha(p["intra"]) == u["intra"], i
+            assert p["ts"] == r["ts"], i
+        if p["type"] == 2:
+            assert sha(p["repadd"]) == u["repadd"] and sha(p["mv_fwd"]) == u["mv"], i
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
+@pytest.mark.parametrize("name", NAMES)
+def test_tensors_equal_javascript_parser(name):
+    cli = os.path.join(ROOT, "mpeg1video-decoder-webgl_amd", "js", "cli.js")
+    out = subprocess.run(["node", cli, "tensors", os.path.join(STREAMS, name + ".jsv")], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    js = json.loads(out.stdout)
+    _, pics = all_pictures(read(name), threads=3)
+    assert len(pics) == len(js["pictures"])
+    for i, (p, j) in enumerate(zip(pics, js["pictures"])):
+        assert p["type"] == j["type"], i
+        keys = [("coefY", "coef_y"), ("coefCb", "coef_cb"), ("coefCr", "coef_cr"), ("qscale", "qscale"), ("intra", "intra")]
+        if p["type"] != 1:
+            keys += [("repadd", "repadd"), ("mvFwd", "mv_fwd")]
+        if p["type"] == 3:
+            keys += [("mvBwd", "mv_bwd"), ("mbDir", "mb_dir")]
+        for a, b in keys:
+            assert sha(p[b]) == j["sha"][a], (i, a)
+        assert p["ts"] == j["ts"], i
+
+
+@pytest.mark.parametrize("name", NAMES)
+def test_result_does_not_depend_on_the_thread_count(name):
+    _, one = all_pictures(read(name), threads=1, dense=False)
+    _, many = all_pictures(read(name), threads=8, dense=False)
+    assert len(one) == len(many)
+    for a, b in zip(one, many):
+        assert np.array_equal(a["grp_off"], b["grp_off"])
+        # entries of a group come in no particular order
+        for g in range(len(a["grp_off"]) - 1):
+            lo, hi = a["grp_off"][g], a["grp_off"][g + 1]
+            assert np.array_equal(np.sort(a["entries"][lo:hi]), np.sort(b["entries"][lo:hi]))
+        for k in ("qscale", "intra", "repadd", "mv_fwd", "mv_bwd", "mb_dir"):
+            assert (a[k] is None) == (b[k] is None) and (a[k] is None or np.array_equal(a[k], b[k])), k
+
+
+def test_sparse_lists_round_trip_through_dense_planes():
+    st, pics = all_pictures(read("leon_synth_352x240"))
+    cw, ch = st.info.coded_width, st.info.coded_height
+    for p in pics[:6]:
+        grp_off, entries = V.sparsify(p["coef_y"], p["coef_cb"], p["coef_cr"], cw, ch)
+        assert np.array_equal(grp_off, p["grp_off"])
+        for g in range(len(grp_off) - 1):
+            lo, hi = grp_off[g], grp_off[g + 1]
+            assert np.array_equal(np.sort(entries[lo:hi]), np.sort(p["entries"][lo:hi]))
+        nz = int(np.count_nonzero(p["coef_y"]) + np.count_nonzero(p["coef_cb"]) + np.count_nonzero(p["coef_cr"]))
+        assert len(p["entries"]) == nz
+        assert np.all(((p["entries"] >> 16) & 1) == 0) and np.all((p["entries"] >> 16) < 1024)
+
+
+def test_key_map_seek_lands_on_the_second_gop():
+    st = V.Stream(read("leon_synth_352x240"))
+    assert st.info.keymap_count == 2
+    assert st.seek(0.6) == 58896                  # = the JavaScript mirror, tests/test_js_parser.py
+    n, first = 0, None
+    while True:
+        p = st.next_picture()
+        if p is None:
+            break
+        first = p["type"] if first is None else first
+        n += 1
+    assert (n, first) == (12, 1)
+    assert st.seek(0.0) == st.seek(-5.0)
+    assert st.next_picture()["type"] == 1
+
+
+def test_raw_elementary_stream_is_accepted():
+    data = bytearray(read("tiny_ip_32x32"))
+    i = data.find(b"\x00\x00\x01\xc3")
+    es = bytes(data[i:]).replace(b"\x00\x00\x01\xc3", b"\x00\x00\x01\xb3")
+    _, a = all_pictures(bytes(data))
+    st, b = all_pictures(es)
+    assert st.info.keymap_count == 0 and len(a) == len(b) == 3
+    for x, y in zip(a, b):
+        assert np.array_equal(x["coef_y"], y["coef_y"]) and np.array_equal(x["qscale"], y["qscale"])
+
+
+def test_damaged_streams_fail_cleanly():
+    lib = V.load()
+    h = ctypes.c_void_p()
+    assert lib.leon_vlc_open(b"\x00" * 4, 4, 1, ctypes.byref(h)) < 0
+    assert lib.leon_vlc_open(b"\x12" * 64, 64, 1, ctypes.byref(h)) < 0 and b"sequence header" in lib.leon_vlc_last_error()
+    data = read("leon_synth_352x240")
+    rng = np.random.default_rng(5)
+    for trial in range(40):
+        d = bytearray(data)
+        if trial % 2:
+            d = d[: int(rng.integers(64, len(d)))]                     # truncation
+        else:
+            for _ in range(int(rng.integers(1, 40))):                  # bit flips behind the headers
+                d[int(rng.integers(200, len(d)))] ^= 1 << int(rng.integers(0, 8))
+        try:
+            st = V.Stream(bytes(d), threads=2)
+        except V.VlcError:
+            continue
+        for _ in range(40):
+            try:
+                if st.next_picture() is None:
+                    break
+            except V.VlcError:
+                pass                      # an error is reported per picture; the parser moves on
