@@ -83,10 +83,29 @@ typedef struct leon_picture {
     const uint8_t* mb_dir; /* B */
 } leon_picture;
 
+/* The same picture with its coefficients as sparse per-group lists -- the format the native
+ * bitstream front end emits (include/leon_vlc.h) -- instead of the three dense
+ * planes the reference uploads.  Equivalent to a leon_picture whose planes hold `level` at every
+ * listed position and 0 elsewhere.  Lists and maps live where `mem` of the call says. */
+typedef struct leon_sparse_picture {
+    int32_t type, out_slot, ref_fwd_slot, ref_bwd_slot;
+    const uint32_t* grp_off;   /* [n_groups+1], n_groups = 2*mbH*ceil(2*mbW/8) + 2*mbH*ceil(mbW/8) */
+    const uint32_t* entries;   /* [n_entries]: (tile byte offset r*128+b*16+c*2) << 16 | (uint16)level */
+    uint32_t n_entries;
+    int32_t reserved;
+    const uint8_t* qscale;
+    const uint8_t* intra;
+    const uint8_t* repadd;
+    const int16_t* mv_fwd;
+    const int16_t* mv_bwd;
+    const uint8_t* mb_dir;
+} leon_sparse_picture;
+
 typedef struct leon_kernel_stats {
     uint64_t launches;        /* timed launches since leon_timing_reset */
     double   total_ms;        /* sum of their HIP-event durations */
-    double   algorithmic_bytes; /* sum over launches of SURVEY.md 8d bytes */
+    double   algorithmic_bytes; /* sum over launches of SURVEY.md 8d bytes (sparse launches: 4 B per entry and
+                                   per group offset in place of the 768 B/MB of dense coefficients) */
     uint64_t macroblocks;     /* sum over launches */
 } leon_kernel_stats;
 
@@ -128,6 +147,12 @@ int leon_submit_batch(leon_decoder* d, const leon_picture* pics, int32_t n, int3
 int leon_batch_create(leon_decoder* d, const leon_picture* pics, int32_t n, leon_batch** out);
 int leon_batch_run(leon_decoder* d, const leon_batch* b);
 void leon_batch_destroy(leon_decoder* d, leon_batch* b);
+
+/* The three calls above for the sparse boundary.  A batch is either all dense or all sparse.
+ * mem = LEON_MEM_HOST: lists and maps are staged per picture (n_entries*4 + offsets instead of
+ * the 6.27 MB of dense planes a 1080p picture uploads, decoders/jsv.js:1237-1243). */
+int leon_submit_sparse(leon_decoder* d, const leon_sparse_picture* pics, int32_t n, int32_t mem);
+int leon_batch_create_sparse(leon_decoder* d, const leon_sparse_picture* pics, int32_t n, leon_batch** out);
 
 /* = renderFrameGL(_frame) (player/easybits.player.js:2787-2858) / YCbCrToRGBA (:2674-2785):
  *   slot -> RGBA8 frame_width x frame_height, tightly packed.  dst_mem says where

@@ -62,6 +62,31 @@ struct TimedLaunch {
 double algo_bytes_per_mb(int type) { return type == LEON_PIC_I ? 1154.0 : type == LEON_PIC_P ? 1542.0 : 1930.0; }
 const double kRgbaBytesPerMb = 1408.0;
 
+// dense or sparse picture as the internals see it
+struct AnyPic {
+    leon_picture p{};            // coef_* unused when sparse
+    const uint32_t* grp_off = nullptr;
+    const uint32_t* entries = nullptr;
+    uint32_t n_entries = 0;
+    bool sparse = false;
+};
+AnyPic any_of(const leon_picture& p)
+{
+    AnyPic a;
+    a.p = p;
+    return a;
+}
+AnyPic any_of(const leon_sparse_picture& q)
+{
+    AnyPic a;
+    a.p.type = q.type; a.p.out_slot = q.out_slot; a.p.ref_fwd_slot = q.ref_fwd_slot; a.p.ref_bwd_slot = q.ref_bwd_slot;
+    a.p.qscale = q.qscale; a.p.intra = q.intra; a.p.repadd = q.repadd;
+    a.p.mv_fwd = q.mv_fwd; a.p.mv_bwd = q.mv_bwd; a.p.mb_dir = q.mb_dir;
+    a.grp_off = q.grp_off; a.entries = q.entries; a.n_entries = q.n_entries;
+    a.sparse = true;
+    return a;
+}
+
 struct Staging {                 // device copy of one host-submitted picture
     char* base = nullptr;
     hipEvent_t done = nullptr;
@@ -75,6 +100,8 @@ struct leon_batch {
     int n = 0;
     int count[3] = {0, 0, 0};     // pictures of type I, P, B
     std::vector<int32_t> out_slots;
+    bool sparse = false;
+    uint64_t entries_of_type[3] = {0, 0, 0};   // sparse: list lengths per type (algorithmic bytes)
 };
 
 struct leon_decoder {
@@ -142,11 +169,18 @@ void upload_tables(leon_decoder* d)
         }
 }
 
-int check_pic(const leon_decoder* d, const leon_picture& p)
+int n_groups_of(const Geom& G) { return 2 * G.tasksY + 2 * G.tasksC; }
+
+int check_pic(const leon_decoder* d, const AnyPic& a)
 {
+    const leon_picture& p = a.p;
     if (p.type < LEON_PIC_I || p.type > LEON_PIC_B) return fail(LEON_ERR_INVALID, "picture type %d", p.type);
     if (p.out_slot < 0 || p.out_slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "out_slot %d", p.out_slot);
-    if (!p.coef_y || !p.coef_cb || !p.coef_cr || !p.qscale || !p.intra) return fail(LEON_ERR_INVALID, "null boundary tensor");
+    if (a.sparse) {
+        if (!a.grp_off || (!a.entries && a.n_entries) || !p.qscale || !p.intra) return fail(LEON_ERR_INVALID, "null boundary tensor");
+        if (a.n_entries > (uint32_t)d->geom.cw * (uint32_t)d->geom.ch * 3u / 2u)
+            return fail(LEON_ERR_INVALID, "%u entries exceed the coefficient count of a picture", a.n_entries);
+    } else if (!p.coef_y || !p.coef_cb || !p.coef_cr || !p.qscale || !p.intra) return fail(LEON_ERR_INVALID, "null boundary tensor");
     if (p.type != LEON_PIC_I) {
         if (p.ref_fwd_slot < 0 || p.ref_fwd_slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "ref_fwd_slot %d", p.ref_fwd_slot);
         if (!p.repadd || !p.mv_fwd) return fail(LEON_ERR_INVALID, "P/B picture without repadd/mv_fwd");
@@ -160,8 +194,12 @@ int check_pic(const leon_decoder* d, const leon_picture& p)
     return LEON_OK;
 }
 
-void fill_desc(const leon_decoder* d, const leon_picture& p, PicDesc& o)
+void fill_desc(const leon_decoder* d, const AnyPic& a, PicDesc& o)
 {
+    const leon_picture& p = a.p;
+    o.grp_off = a.grp_off;
+    o.entries = a.entries;
+    o.n_entries = a.n_entries;
     o.coef[0] = p.coef_y;
     o.coef[1] = p.coef_cb;
     o.coef[2] = p.coef_cr;
@@ -175,7 +213,6 @@ void fill_desc(const leon_decoder* d, const leon_picture& p, PicDesc& o)
     o.ref_fwd = p.type != LEON_PIC_I ? d->d_slots + (size_t)p.ref_fwd_slot * d->slot_stride : nullptr;
     o.ref_bwd = p.type == LEON_PIC_B ? d->d_slots + (size_t)p.ref_bwd_slot * d->slot_stride : nullptr;
     o.type = p.type;
-    o.pad_ = 0;
 }
 
 // a submit that overwrites a slot still being converted on the second stream waits for it
@@ -192,7 +229,7 @@ int guard_pending_conversions(leon_decoder* d, const int32_t* out_slots, int n)
 }
 
 // one launch of the type-specialised kernel over n pictures of that type
-int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n)
+int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, bool sparse = false, uint64_t entries = 0)
 {
     Geom G = d->geom;
     G.n_pics = n;
@@ -209,15 +246,23 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n)
         tl.pic_type = type;
         tl.mbs = (uint64_t)d->geom.mbw * d->geom.mbh * (uint64_t)n;
         tl.bytes = algo_bytes_per_mb(type) * (double)tl.mbs;
+        if (sparse)   // the lists replace the 768 B/MB of dense coefficients
+            tl.bytes += 4.0 * (double)entries + 4.0 * (double)(n_groups_of(d->geom) + 1) * n - 768.0 * (double)tl.mbs;
         HIP_TRY(hipEventRecord(tl.a, d->stream));
     }
     const dim3 grid(G.n_wg), block(64 * kWavesPerWG);
     // LEON_DEBUG_LDS_PAD (bytes): extra dynamic LDS per workgroup = an occupancy throttle for experiments
     static const size_t lds_pad = getenv("LEON_DEBUG_LDS_PAD") ? (size_t)atol(getenv("LEON_DEBUG_LDS_PAD")) : 0;
     const size_t lds = kWavesPerWG * kLdsPerWave + lds_pad;
-    if (type == LEON_PIC_I) hipLaunchKernelGGL(k_recon<1>, grid, block, lds, d->stream, d_descs, G, d->d_tables);
-    else if (type == LEON_PIC_P) hipLaunchKernelGGL(k_recon<2>, grid, block, lds, d->stream, d_descs, G, d->d_tables);
-    else hipLaunchKernelGGL(k_recon<3>, grid, block, lds, d->stream, d_descs, G, d->d_tables);
+    if (!sparse) {
+        if (type == LEON_PIC_I) hipLaunchKernelGGL((k_recon<1, false>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+        else if (type == LEON_PIC_P) hipLaunchKernelGGL((k_recon<2, false>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+        else hipLaunchKernelGGL((k_recon<3, false>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+    } else {
+        if (type == LEON_PIC_I) hipLaunchKernelGGL((k_recon<1, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+        else if (type == LEON_PIC_P) hipLaunchKernelGGL((k_recon<2, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+        else hipLaunchKernelGGL((k_recon<3, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+    }
     HIP_TRY(hipGetLastError());
     if (d->timing) {
         HIP_TRY(hipEventRecord(tl.b, d->stream));
@@ -227,12 +272,12 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n)
 }
 
 // descriptors sorted by type ([I..][P..][B..]); one launch per type present
-int launch_recon(leon_decoder* d, const PicDesc* d_descs, const int count[3])
+int launch_recon(leon_decoder* d, const PicDesc* d_descs, const int count[3], bool sparse = false, const uint64_t* entries = nullptr)
 {
     int at = 0;
     for (int k = 0; k < 3; k++) {
         if (count[k] > 0) {
-            int rc = launch_recon_type(d, k + 1, d_descs + at, count[k]);
+            int rc = launch_recon_type(d, k + 1, d_descs + at, count[k], sparse, entries ? entries[k] : 0);
             if (rc != LEON_OK) return rc;
         }
         at += count[k];
@@ -241,12 +286,16 @@ int launch_recon(leon_decoder* d, const PicDesc* d_descs, const int count[3])
 }
 
 // fill `out` with the descriptors of pics sorted by type, and the per-type counts
-void sorted_descs(const leon_decoder* d, const leon_picture* pics, int n, PicDesc* out, int count[3])
+void sorted_descs(const leon_decoder* d, const AnyPic* pics, int n, PicDesc* out, int count[3], uint64_t entries[3])
 {
     count[0] = count[1] = count[2] = 0;
-    for (int i = 0; i < n; i++) count[pics[i].type - 1]++;
+    entries[0] = entries[1] = entries[2] = 0;
+    for (int i = 0; i < n; i++) {
+        count[pics[i].p.type - 1]++;
+        entries[pics[i].p.type - 1] += pics[i].n_entries;
+    }
     int at[3] = {0, count[0], count[0] + count[1]};
-    for (int i = 0; i < n; i++) fill_desc(d, pics[i], out[at[pics[i].type - 1]++]);
+    for (int i = 0; i < n; i++) fill_desc(d, pics[i], out[at[pics[i].p.type - 1]++]);
 }
 
 // reserve n consecutive descriptors in the ring (wrap = wait for the previous lap)
@@ -338,7 +387,8 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
     if (hipHostMalloc((void**)&d->h_slot_ids, sizeof(int32_t) * leon_decoder::kSlotIdRing) != hipSuccess) return bail("pinned slot ids");
     // staging for host-memory pictures: coef planes (2 bytes/sample) + 5 byte maps + 2 vector maps
     size_t mbs = (size_t)G.mbw * G.mbh;
-    d->stage_bytes = d->plane_bytes * 2 + 4 * ((mbs + 255) / 256 * 256) + 2 * ((mbs * 4 + 255) / 256 * 256) + 1024;
+    // coefficients: dense planes (2 B each) or, at worst, one 4-byte entry each plus the group offsets
+    d->stage_bytes = d->plane_bytes * 4 + ((size_t)n_groups_of(d->geom) + 1) * 4 + 1024 + 4 * ((mbs + 255) / 256 * 256) + 2 * ((mbs * 4 + 255) / 256 * 256) + 1024;
     if (hipStreamSynchronize(d->stream) != hipSuccess) return bail("create sync");
     *out = d;
     return LEON_OK;
@@ -416,54 +466,27 @@ int leon_free_decoded_slots(leon_decoder* d)
     return LEON_OK;
 }
 
-int leon_submit_batch(leon_decoder* d, const leon_picture* pics, int32_t n, int32_t mem)
-{
-    if (!d || !pics || n <= 0) return fail(LEON_ERR_INVALID, "bad batch");
-    HIP_TRY(hipSetDevice(d->dev));
-    for (int i = 0; i < n; i++) {
-        int rc = check_pic(d, pics[i]);
-        if (rc != LEON_OK) return rc;
-    }
-    if (n <= 64)   // pictures of one launch must be mutually independent (O(n^2): small batches only)
-        for (int i = 0; i < n; i++)
-            for (int j = 0; j < i; j++)
-                if (pics[j].out_slot == pics[i].out_slot ||
-                    (pics[i].type != LEON_PIC_I && pics[i].ref_fwd_slot == pics[j].out_slot) ||
-                    (pics[i].type == LEON_PIC_B && pics[i].ref_bwd_slot == pics[j].out_slot) ||
-                    (pics[j].type != LEON_PIC_I && pics[j].ref_fwd_slot == pics[i].out_slot) ||
-                    (pics[j].type == LEON_PIC_B && pics[j].ref_bwd_slot == pics[i].out_slot))
-                    return fail(LEON_ERR_INVALID, "pictures %d and %d of one batch depend on each other", j, i);
-    if (mem == LEON_MEM_HOST) {
-        if (n != 1) {
-            for (int i = 0; i < n; i++) {
-                int rc = leon_submit_picture(d, &pics[i]);
-                if (rc != LEON_OK) return rc;
-            }
-            return LEON_OK;
-        }
-        return leon_submit_picture(d, pics);
-    }
-    int at = 0;
-    int rc = reserve_descs(d, n, at);
-    if (rc != LEON_OK) return rc;
-    {
-        std::vector<int32_t> outs(n);
-        for (int i = 0; i < n; i++) outs[i] = pics[i].out_slot;
-        rc = guard_pending_conversions(d, outs.data(), n);
-        if (rc != LEON_OK) return rc;
-    }
-    int count[3];
-    sorted_descs(d, pics, n, d->h_desc_pinned + at, count);
-    HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc) * n, hipMemcpyHostToDevice, d->stream));
-    return launch_recon(d, d->d_desc_ring + at, count);
-}
+}  // extern "C"
 
-int leon_submit_picture(leon_decoder* d, const leon_picture* pic)
+namespace {
+
+// = IDCT_GL for one picture whose arrays are in host memory: stage, then reconstruct
+int submit_picture_any(leon_decoder* d, const AnyPic& pic)
 {
-    if (!d || !pic) return fail(LEON_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(d->dev));
-    int rc = check_pic(d, *pic);
+    int rc = check_pic(d, pic);
     if (rc != LEON_OK) return rc;
+    const Geom& G = d->geom;
+    const size_t n_groups = (size_t)n_groups_of(G);
+    if (pic.sparse) {
+        // host lists can be checked: offsets ascending and closed by the list length
+        uint32_t prev = 0;
+        for (size_t g = 0; g <= n_groups; g++) {
+            if (pic.grp_off[g] < prev) return fail(LEON_ERR_INVALID, "grp_off is not ascending at group %zu", g);
+            prev = pic.grp_off[g];
+        }
+        if (prev != pic.n_entries) return fail(LEON_ERR_INVALID, "grp_off ends at %u, n_entries is %u", prev, pic.n_entries);
+    }
     Staging& s = d->stages[d->next_stage];
     d->next_stage = (d->next_stage + 1) % leon_decoder::kStages;
     if (!s.base) {
@@ -471,44 +494,98 @@ int leon_submit_picture(leon_decoder* d, const leon_picture* pic)
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
     if (s.busy) HIP_TRY(hipEventSynchronize(s.done));
-    const Geom& G = d->geom;
     size_t ny = (size_t)G.cw * G.ch, nc = ny >> 2, mbs = (size_t)G.mbw * G.mbh;
     size_t mpad = (mbs + 255) / 256 * 256, vpad = (mbs * 4 + 255) / 256 * 256;
     char* p = s.base;
-    leon_picture dp = *pic;
+    AnyPic dp = pic;
     auto put = [&](const void* src, size_t bytes, size_t reserve) -> const void* {
         char* at = p;
         p += reserve;
-        if (src) hipMemcpyAsync(at, src, bytes, hipMemcpyHostToDevice, d->stream);
+        if (src && bytes) hipMemcpyAsync(at, src, bytes, hipMemcpyHostToDevice, d->stream);
         return src ? at : nullptr;
     };
-    dp.coef_y = (const int16_t*)put(pic->coef_y, ny * 2, ny * 2);
-    dp.coef_cb = (const int16_t*)put(pic->coef_cb, nc * 2, nc * 2);
-    dp.coef_cr = (const int16_t*)put(pic->coef_cr, nc * 2, nc * 2);
-    dp.qscale = (const uint8_t*)put(pic->qscale, mbs, mpad);
-    dp.intra = (const uint8_t*)put(pic->intra, mbs, mpad);
-    dp.repadd = (const uint8_t*)put(pic->type != LEON_PIC_I ? pic->repadd : nullptr, mbs, mpad);
-    dp.mb_dir = (const uint8_t*)put(pic->type == LEON_PIC_B ? pic->mb_dir : nullptr, mbs, mpad);
-    dp.mv_fwd = (const int16_t*)put(pic->type != LEON_PIC_I ? pic->mv_fwd : nullptr, mbs * 4, vpad);
-    dp.mv_bwd = (const int16_t*)put(pic->type == LEON_PIC_B ? pic->mv_bwd : nullptr, mbs * 4, vpad);
+    auto pad256 = [](size_t v) { return (v + 255) / 256 * 256; };
+    if (pic.sparse) {
+        dp.grp_off = (const uint32_t*)put(pic.grp_off, (n_groups + 1) * 4, pad256((n_groups + 1) * 4));
+        dp.entries = (const uint32_t*)put(pic.entries ? (const void*)pic.entries : (const void*)pic.grp_off,
+                                          (size_t)pic.n_entries * 4, pad256((size_t)pic.n_entries * 4 + 4));
+    } else {
+        dp.p.coef_y = (const int16_t*)put(pic.p.coef_y, ny * 2, ny * 2);
+        dp.p.coef_cb = (const int16_t*)put(pic.p.coef_cb, nc * 2, nc * 2);
+        dp.p.coef_cr = (const int16_t*)put(pic.p.coef_cr, nc * 2, nc * 2);
+    }
+    const int type = pic.p.type;
+    dp.p.qscale = (const uint8_t*)put(pic.p.qscale, mbs, mpad);
+    dp.p.intra = (const uint8_t*)put(pic.p.intra, mbs, mpad);
+    dp.p.repadd = (const uint8_t*)put(type != LEON_PIC_I ? pic.p.repadd : nullptr, mbs, mpad);
+    dp.p.mb_dir = (const uint8_t*)put(type == LEON_PIC_B ? pic.p.mb_dir : nullptr, mbs, mpad);
+    dp.p.mv_fwd = (const int16_t*)put(type != LEON_PIC_I ? pic.p.mv_fwd : nullptr, mbs * 4, vpad);
+    dp.p.mv_bwd = (const int16_t*)put(type == LEON_PIC_B ? pic.p.mv_bwd : nullptr, mbs * 4, vpad);
     HIP_TRY(hipGetLastError());
     int at = 0;
     rc = reserve_descs(d, 1, at);
     if (rc != LEON_OK) return rc;
     fill_desc(d, dp, d->h_desc_pinned[at]);
-    rc = guard_pending_conversions(d, &dp.out_slot, 1);
+    rc = guard_pending_conversions(d, &dp.p.out_slot, 1);
     if (rc != LEON_OK) return rc;
     HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc), hipMemcpyHostToDevice, d->stream));
-    rc = launch_recon_type(d, dp.type, d->d_desc_ring + at, 1);
+    rc = launch_recon_type(d, type, d->d_desc_ring + at, 1, pic.sparse, pic.n_entries);
     if (rc != LEON_OK) return rc;
     HIP_TRY(hipEventRecord(s.done, d->stream));
     s.busy = true;
     return LEON_OK;
 }
 
-int leon_batch_create(leon_decoder* d, const leon_picture* pics, int32_t n, leon_batch** out)
+int check_batch(const leon_decoder* d, const AnyPic* pics, int n)
 {
-    if (!d || !pics || n <= 0 || !out) return fail(LEON_ERR_INVALID, "bad batch");
+    for (int i = 0; i < n; i++) {
+        int rc = check_pic(d, pics[i]);
+        if (rc != LEON_OK) return rc;
+    }
+    if (n <= 64)   // pictures of one launch must be mutually independent (O(n^2): small batches only)
+        for (int i = 0; i < n; i++)
+            for (int j = 0; j < i; j++) {
+                const leon_picture &a = pics[j].p, &b = pics[i].p;
+                if (a.out_slot == b.out_slot ||
+                    (b.type != LEON_PIC_I && b.ref_fwd_slot == a.out_slot) ||
+                    (b.type == LEON_PIC_B && b.ref_bwd_slot == a.out_slot) ||
+                    (a.type != LEON_PIC_I && a.ref_fwd_slot == b.out_slot) ||
+                    (a.type == LEON_PIC_B && a.ref_bwd_slot == b.out_slot))
+                    return fail(LEON_ERR_INVALID, "pictures %d and %d of one batch depend on each other", j, i);
+            }
+    return LEON_OK;
+}
+
+int submit_batch_any(leon_decoder* d, const AnyPic* pics, int n, int mem)
+{
+    HIP_TRY(hipSetDevice(d->dev));
+    int rc = check_batch(d, pics, n);
+    if (rc != LEON_OK) return rc;
+    if (mem == LEON_MEM_HOST) {
+        for (int i = 0; i < n; i++) {
+            rc = submit_picture_any(d, pics[i]);
+            if (rc != LEON_OK) return rc;
+        }
+        return LEON_OK;
+    }
+    int at = 0;
+    rc = reserve_descs(d, n, at);
+    if (rc != LEON_OK) return rc;
+    {
+        std::vector<int32_t> outs(n);
+        for (int i = 0; i < n; i++) outs[i] = pics[i].p.out_slot;
+        rc = guard_pending_conversions(d, outs.data(), n);
+        if (rc != LEON_OK) return rc;
+    }
+    int count[3];
+    uint64_t entries[3];
+    sorted_descs(d, pics, n, d->h_desc_pinned + at, count, entries);
+    HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc) * n, hipMemcpyHostToDevice, d->stream));
+    return launch_recon(d, d->d_desc_ring + at, count, pics[0].sparse, entries);
+}
+
+int batch_create_any(leon_decoder* d, const AnyPic* pics, int n, leon_batch** out)
+{
     HIP_TRY(hipSetDevice(d->dev));
     *out = nullptr;
     std::vector<PicDesc> h(n);
@@ -519,9 +596,10 @@ int leon_batch_create(leon_decoder* d, const leon_picture* pics, int32_t n, leon
     leon_batch* b = new (std::nothrow) leon_batch();
     if (!b) return fail(LEON_ERR_NOMEM, "out of host memory");
     b->n = n;
-    sorted_descs(d, pics, n, h.data(), b->count);
+    b->sparse = pics[0].sparse;
+    sorted_descs(d, pics, n, h.data(), b->count, b->entries_of_type);
     b->out_slots.resize(n);
-    for (int i = 0; i < n; i++) b->out_slots[i] = pics[i].out_slot;
+    for (int i = 0; i < n; i++) b->out_slots[i] = pics[i].p.out_slot;
     if (hipMalloc(&b->d_descs, sizeof(PicDesc) * n) != hipSuccess) {
         delete b;
         return fail(LEON_ERR_NOMEM, "descriptor allocation failed");
@@ -536,13 +614,55 @@ int leon_batch_create(leon_decoder* d, const leon_picture* pics, int32_t n, leon
     return LEON_OK;
 }
 
+template <typename P>
+std::vector<AnyPic> wrap(const P* pics, int n)
+{
+    std::vector<AnyPic> v((size_t)n);
+    for (int i = 0; i < n; i++) v[(size_t)i] = any_of(pics[i]);
+    return v;
+}
+
+}  // namespace
+
+extern "C" {
+
+int leon_submit_batch(leon_decoder* d, const leon_picture* pics, int32_t n, int32_t mem)
+{
+    if (!d || !pics || n <= 0) return fail(LEON_ERR_INVALID, "bad batch");
+    return submit_batch_any(d, wrap(pics, n).data(), n, mem);
+}
+
+int leon_submit_sparse(leon_decoder* d, const leon_sparse_picture* pics, int32_t n, int32_t mem)
+{
+    if (!d || !pics || n <= 0) return fail(LEON_ERR_INVALID, "bad batch");
+    return submit_batch_any(d, wrap(pics, n).data(), n, mem);
+}
+
+int leon_submit_picture(leon_decoder* d, const leon_picture* pic)
+{
+    if (!d || !pic) return fail(LEON_ERR_INVALID, "null argument");
+    return submit_picture_any(d, any_of(*pic));
+}
+
+int leon_batch_create(leon_decoder* d, const leon_picture* pics, int32_t n, leon_batch** out)
+{
+    if (!d || !pics || n <= 0 || !out) return fail(LEON_ERR_INVALID, "bad batch");
+    return batch_create_any(d, wrap(pics, n).data(), n, out);
+}
+
+int leon_batch_create_sparse(leon_decoder* d, const leon_sparse_picture* pics, int32_t n, leon_batch** out)
+{
+    if (!d || !pics || n <= 0 || !out) return fail(LEON_ERR_INVALID, "bad batch");
+    return batch_create_any(d, wrap(pics, n).data(), n, out);
+}
+
 int leon_batch_run(leon_decoder* d, const leon_batch* b)
 {
     if (!d || !b) return fail(LEON_ERR_INVALID, "null argument");
     HIP_TRY(hipSetDevice(d->dev));
     int rc = guard_pending_conversions(d, b->out_slots.data(), b->n);
     if (rc != LEON_OK) return rc;
-    return launch_recon(d, b->d_descs, b->count);
+    return launch_recon(d, b->d_descs, b->count, b->sparse, b->entries_of_type);
 }
 
 void leon_batch_destroy(leon_decoder* d, leon_batch* b)

@@ -49,7 +49,9 @@ struct PicDesc {                 // one per picture of a batch, device resident
     const uint8_t* ref_fwd;
     const uint8_t* ref_bwd;
     int32_t        type;         // 1 I, 2 P, 3 B
-    int32_t        pad_;
+    uint32_t       n_entries;    // sparse boundary: entries[] length
+    const uint32_t* grp_off;     // sparse boundary (include/leon_vlc.h): prefix offsets per 64x8 group
+    const uint32_t* entries;     // (tile byte offset << 16) | level
 };
 
 struct Geom {
@@ -418,7 +420,7 @@ __device__ __forceinline__ uint32_t pred_x256(uint32_t pred)
 // Everything that depends only on the macroblock -- maps, vectors and their half-pel
 // decomposition, quantiser tables, the in-picture test -- is computed once per task.
 
-template <int TYPE, bool CHROMA>
+template <int TYPE, bool CHROMA, bool SPARSE>
 __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, const Tables* __restrict__ Tg,
                                            int Rt, int g, char* lds, int lane)
 {
@@ -448,7 +450,30 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     // a table indexed by the scale would put a second dependent memory round trip here)
     const int R0 = CHROMA ? Rt : 2 * Rt;
     const uint32_t coef_voff = (2u * ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)(8 * Qld))) | (ld_ok ? 0u : kOobBit);
-    v4i cv_next = buf_load_v4i_s(buf_rsrc(pd.coef[CHROMA ? 1 : 0]), coef_voff, 0u);
+    v4i cv_next = {0, 0, 0, 0};
+    // sparse boundary: the two groups of the task are two runs of entries[]; the first 64
+    // entries of each are requested here (one dword per lane), longer runs loop in stage 1
+    uint32_t ent_first[2] = {0u, 0u}, ent_start[2] = {0u, 0u}, ent_count[2] = {0u, 0u};
+    // a resource of exactly n_entries dwords: indices past the list read 0, whatever grp_off says
+    const __amdgpu_buffer_rsrc_t ent_rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void*)(SPARSE ? pd.entries : nullptr), 0, SPARSE ? (int)(pd.n_entries * 4u) : 0, 0x00020000);
+    if constexpr (SPARSE) {
+        const uint32_t nY = 2u * (uint32_t)G.tasksY, nC = (uint32_t)G.tasksC;
+        const uint32_t gid0 = CHROMA ? nY + (uint32_t)(Rt * G.gC + g) : (uint32_t)(2 * Rt * G.gY + g);
+        const uint32_t gid1 = CHROMA ? gid0 + nC : gid0 + (uint32_t)G.gY;
+        const uint32_t* go = pd.grp_off;                     // wave-uniform index: scalar loads
+        const uint32_t gid[2] = {gid0, gid1};
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const uint32_t s0 = go[gid[h]], e0 = go[gid[h] + 1];
+            ent_start[h] = s0;
+            ent_count[h] = e0 > s0 ? min(e0 - s0, 512u) : 0u;      // a group holds at most 8*64 coefficients
+            ent_first[h] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                ent_rs, (int)(((s0 + (uint32_t)lane) * 4u) | ((uint32_t)lane < ent_count[h] ? 0u : kOobBit)), 0, 0);
+        }
+    } else {
+        cv_next = buf_load_v4i_s(buf_rsrc(pd.coef[CHROMA ? 1 : 0]), coef_voff, 0u);
+    }
     const v2u mI = ldg<v2u>(T, (uint32_t)c * 8u), mN = ldg<v2u>(T, 64u + (uint32_t)c * 8u);
     const v2u pm8 = ldg<v2u>(T, 128u + (uint32_t)c * 8u);
     const uint32_t mb = (uint32_t)(CHROMA ? Rt * G.mbw + Qs : Rt * G.mbw + (Qs >> 1));
@@ -520,15 +545,13 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     }
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-        const int comp = CHROMA ? 1 + half : 0;
-        const int R = CHROMA ? Rt : 2 * Rt + half;
         const uint32_t plane_off = CHROMA ? (half == 0 ? ysz : ysz + (ysz >> 2)) : 0u;
-        const int y = 8 * R + hi3;
 
         // ---- stage 0: this half's coefficient rows were requested a half earlier; request the
         //      next half's now so that their HBM latency hides behind this half's arithmetic
         const v4i cv = cv_next;
-        {   // always issued; in the last half the resource has no records, so nothing is fetched
+        if constexpr (!SPARSE) {
+            // always issued; in the last half the resource has no records, so nothing is fetched
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)pd.coef[CHROMA ? 2 : 0], 0, half == 0 ? 0x7fffffff : 0, 0x00020000);
             cv_next = buf_load_v4i_s(rs, coef_voff, 2u * half_step);
@@ -536,10 +559,25 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         RefRows rf = rfh[half], rb = rbh[half];
 
         // ---- stage 1: coefficient rows -> LDS tile [r][b][c] ------------------------------
-        *reinterpret_cast<v4i*>(lds_wr) = cv;
+        *reinterpret_cast<v4i*>(lds_wr) = cv;                 // sparse: cv == 0 clears the tile
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if constexpr (SPARSE) {
+            // scatter the group's entries into the cleared tile; the offset is masked to the tile
+            uint32_t e = ent_first[half];
+            if (e != 0u) *reinterpret_cast<short*>(lds + ((e >> 16) & 1022u)) = (short)e;
+#pragma unroll 1
+            for (uint32_t k = 64u; k < ent_count[half]; k += 64u) {     // wave-uniform, rare
+                const uint32_t idx = k + (uint32_t)lane;
+                e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
+                    ent_rs, (int)(((ent_start[half] + idx) * 4u) | (idx < ent_count[half] ? 0u : kOobBit)), 0, 0);
+                if (e != 0u) *reinterpret_cast<short*>(lds + ((e >> 16) & 1022u)) = (short)e;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
 
         int t[8];
         int X[8];
@@ -653,24 +691,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int n)
     return x * q + min(x, r) + j;
 }
 
-template <int TYPE>
+template <int TYPE, bool SPARSE>
 __device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G, const Tables* T,
                                                int t, char* lds, int lane)
 {
     if (t < G.tasksY) {
         int Rt = div_inv(t, G.inv_gY), g = t - Rt * G.gY;
-        recon_task<TYPE, false>(pd, G, T, Rt, g, lds, lane);
+        recon_task<TYPE, false, SPARSE>(pd, G, T, Rt, g, lds, lane);
     } else {
         t -= G.tasksY;
         int Rt = div_inv(t, G.inv_gC), g = t - Rt * G.gC;
-        recon_task<TYPE, true>(pd, G, T, Rt, g, lds, lane);
+        recon_task<TYPE, true, SPARSE>(pd, G, T, Rt, g, lds, lane);
     }
 }
 
 // One kernel per picture type: the register budget of the I and P paths is not held hostage
 // by the two predictors of the B path (VGPRs decide waves per SIMD), and a launch only ever
 // contains pictures of one type.
-template <int TYPE>
+template <int TYPE, bool SPARSE>
 __global__ __launch_bounds__(256) void k_recon(const PicDesc* __restrict__ descs, Geom G,
                                                const Tables* __restrict__ T)
 {
@@ -682,7 +720,7 @@ __global__ __launch_bounds__(256) void k_recon(const PicDesc* __restrict__ descs
     const int t = (wg - pic * G.wg_per_pic) * kWavesPerWG + wave;
     if (t >= G.tasks_per_pic) return;
     char* lds = smem + wave * kLdsPerWave;
-    recon_dispatch<TYPE>(descs[pic], G, T, t, lds, lane);
+    recon_dispatch<TYPE, SPARSE>(descs[pic], G, T, t, lds, lane);
 }
 
 // ---- K3: YCbCr 4:2:0 -> RGBA8 ------------------------------------------------------

@@ -23,6 +23,7 @@ SYMBOLS = [
     "leon_abi_version", "leon_last_error", "leon_create", "leon_destroy", "leon_set_quant_matrices",
     "leon_acquire_slot", "leon_release_slot", "leon_free_decoded_slots", "leon_submit_picture",
     "leon_submit_batch", "leon_batch_create", "leon_batch_run", "leon_batch_destroy",
+    "leon_submit_sparse", "leon_batch_create_sparse",
     "leon_convert_rgba", "leon_convert_rgba_batch", "leon_read_planes", "leon_write_planes",
     "leon_slot_device_ptr", "leon_sync", "leon_set_overlap_convert", "leon_timing_enable", "leon_timing_reset", "leon_timing_get",
     "leon_measure_copy_bandwidth",
@@ -47,6 +48,13 @@ class Picture(C.Structure):
                 ("coef_cr", C.c_void_p), ("qscale", C.c_void_p), ("intra", C.c_void_p),
                 ("repadd", C.c_void_p), ("mv_fwd", C.c_void_p), ("mv_bwd", C.c_void_p),
                 ("mb_dir", C.c_void_p)]
+
+
+class SparsePicture(C.Structure):
+    _fields_ = [("type", C.c_int32), ("out_slot", C.c_int32), ("ref_fwd_slot", C.c_int32),
+                ("ref_bwd_slot", C.c_int32), ("grp_off", C.c_void_p), ("entries", C.c_void_p),
+                ("n_entries", C.c_uint32), ("reserved", C.c_int32), ("qscale", C.c_void_p), ("intra", C.c_void_p),
+                ("repadd", C.c_void_p), ("mv_fwd", C.c_void_p), ("mv_bwd", C.c_void_p), ("mb_dir", C.c_void_p)]
 
 
 class KernelStats(C.Structure):
@@ -85,6 +93,8 @@ def load():
     lib.leon_submit_picture.argtypes = [C.c_void_p, C.POINTER(Picture)]
     lib.leon_submit_batch.argtypes = [C.c_void_p, C.POINTER(Picture), C.c_int32, C.c_int32]
     lib.leon_batch_create.argtypes = [C.c_void_p, C.POINTER(Picture), C.c_int32, C.POINTER(C.c_void_p)]
+    lib.leon_submit_sparse.argtypes = [C.c_void_p, C.POINTER(SparsePicture), C.c_int32, C.c_int32]
+    lib.leon_batch_create_sparse.argtypes = [C.c_void_p, C.POINTER(SparsePicture), C.c_int32, C.POINTER(C.c_void_p)]
     lib.leon_batch_run.argtypes = [C.c_void_p, C.c_void_p]
     lib.leon_batch_destroy.argtypes = [C.c_void_p, C.c_void_p]
     lib.leon_batch_destroy.restype = None
@@ -130,6 +140,30 @@ def make_picture(ptype, out_slot, coef_y, coef_cb, coef_cr, qscale, intra, repad
     p.coef_y = _hostptr(coef_y, np.int16, keep)
     p.coef_cb = _hostptr(coef_cb, np.int16, keep)
     p.coef_cr = _hostptr(coef_cr, np.int16, keep)
+    p.qscale = _hostptr(qscale, np.uint8, keep)
+    p.intra = _hostptr(intra, np.uint8, keep)
+    p.repadd = _hostptr(repadd, np.uint8, keep)
+    p.mv_fwd = _hostptr(mv_fwd, np.int16, keep)
+    p.mv_bwd = _hostptr(mv_bwd, np.int16, keep)
+    p.mb_dir = _hostptr(mb_dir, np.uint8, keep)
+    p._keep = keep
+    return p
+
+
+def make_sparse_picture(ptype, out_slot, grp_off, entries, n_entries, qscale, intra, repadd=None, mv_fwd=None,
+                        mv_bwd=None, mb_dir=None, ref_fwd_slot=-1, ref_bwd_slot=-1, keep=None, device=False):
+    """The sparse-boundary twin of make_picture (lists in the format of include/leon_vlc.h)."""
+    p = SparsePicture()
+    p.type, p.out_slot, p.ref_fwd_slot, p.ref_bwd_slot = ptype, out_slot, ref_fwd_slot, ref_bwd_slot
+    p.n_entries = int(n_entries)
+    if device:
+        vals = (grp_off, entries, qscale, intra, repadd, mv_fwd, mv_bwd, mb_dir)
+        (p.grp_off, p.entries, p.qscale, p.intra, p.repadd, p.mv_fwd, p.mv_bwd, p.mb_dir) = \
+            [None if v is None else int(v) for v in vals]
+        return p
+    keep = keep if keep is not None else []
+    p.grp_off = _hostptr(grp_off, np.uint32, keep)
+    p.entries = _hostptr(entries, np.uint32, keep)
     p.qscale = _hostptr(qscale, np.uint8, keep)
     p.intra = _hostptr(intra, np.uint8, keep)
     p.repadd = _hostptr(repadd, np.uint8, keep)
@@ -190,6 +224,16 @@ class Decoder:
         arr = (Picture * len(pics))(*pics)
         b = C.c_void_p()
         _chk(self.lib.leon_batch_create(self.h, arr, len(pics), C.byref(b)))
+        return b
+
+    def submit_sparse(self, pics, mem=MEM_HOST):
+        arr = (SparsePicture * len(pics))(*pics)
+        _chk(self.lib.leon_submit_sparse(self.h, arr, len(pics), mem))
+
+    def batch_create_sparse(self, pics):
+        arr = (SparsePicture * len(pics))(*pics)
+        b = C.c_void_p()
+        _chk(self.lib.leon_batch_create_sparse(self.h, arr, len(pics), C.byref(b)))
         return b
 
     def batch_run(self, b):

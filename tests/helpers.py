@@ -42,3 +42,18 @@ def hip_submit(L, dec, t, keep):
 
 def planes_flat(y, cb, cr):
     return np.concatenate([y.ravel(), cb.ravel(), cr.ravel()])
+
+
+def hip_submit_sparse(L, dec, t, keep, cw, ch):
+    """The same picture through the sparse boundary (include/leon_vlc.h lists)."""
+    import leon_vlc_ctypes as V
+    if "grp_off" in t and t.get("entries") is not None:
+        grp_off, entries = t["grp_off"], t["entries"]
+    else:
+        grp_off, entries = V.sparsify(t["coef_y"], t["coef_cb"], t["coef_cr"], cw, ch)
+    p = L.make_sparse_picture(t["type"], t["slot"], grp_off, entries, len(entries), t["qscale"], t["intra"],
+                              repadd=t.get("repadd"), mv_fwd=t.get("mv_fwd"), mv_bwd=t.get("mv_bwd"),
+                              mb_dir=t.get("mb_dir"),
+                              ref_fwd_slot=-1 if t.get("ref_fwd") is None else t["ref_fwd"],
+                              ref_bwd_slot=-1 if t.get("ref_bwd") is None else t["ref_bwd"], keep=keep)
+    dec.submit_sparse([p], L.MEM_HOST)
