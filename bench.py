@@ -31,7 +31,7 @@ GOP_LEN = 12
 HBM_PEAK_GBPS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s (spec)
 
 
-def build_workload(L, S, dec, torch, gops, seed):
+def build_workload(L, S, dec, torch, gops, seed, sparse=False):
     """One unique synthetic GOP on the host, replicated into `gops` independent device-resident
     GOPs (own coefficient planes, own slots).  Returns (levels, slot ids in display order)."""
     rng = np.random.default_rng(seed)
@@ -41,8 +41,14 @@ def build_workload(L, S, dec, torch, gops, seed):
     for ptype, disp, f, b in gop:
         force = 2 if (ptype == S.PIC_B and f is None) else None
         host[disp] = S.make_picture(rng, CW, CH, ptype, force_dir=force)
-    dev_unique = {d: {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in t.items()
-                      if isinstance(v, np.ndarray)} for d, t in host.items()}
+        if sparse:   # the same coefficients as per-group entry lists (include/leon_vlc.h)
+            import leon_vlc_ctypes as V
+            t = host[disp]
+            t["grp_off"], t["entries"] = V.sparsify(t["coef_y"], t["coef_cb"], t["coef_cr"], CW, CH)
+    dense_keys = ("coef_y", "coef_cb", "coef_cr")
+    as_dev = lambda v: torch.from_numpy(np.ascontiguousarray(v).view(np.int32) if v.dtype == np.uint32 else np.ascontiguousarray(v)).cuda()
+    dev_unique = {d: {k: as_dev(v) for k, v in t.items()
+                      if isinstance(v, np.ndarray) and not (sparse and k in dense_keys)} for d, t in host.items()}
     keep = [dev_unique]
     batches = []
     for lv in levels:
@@ -57,12 +63,16 @@ def build_workload(L, S, dec, torch, gops, seed):
                 ptr = lambda k: d[k].data_ptr() if k in d else None
                 base = g * GOP_LEN
                 fwd = f if f is not None else b
-                pics.append(L.make_picture(
-                    ptype, base + disp, ptr("coef_y"), ptr("coef_cb"), ptr("coef_cr"), ptr("qscale"),
-                    ptr("intra"), ptr("repadd"), ptr("mv_fwd"), ptr("mv_bwd"), ptr("mb_dir"),
-                    ref_fwd_slot=-1 if fwd is None else base + fwd,
-                    ref_bwd_slot=-1 if b is None else base + b, device=True))
-        batches.append(dec.batch_create(pics))
+                slots = dict(ref_fwd_slot=-1 if fwd is None else base + fwd, ref_bwd_slot=-1 if b is None else base + b)
+                if sparse:
+                    pics.append(L.make_sparse_picture(
+                        ptype, base + disp, ptr("grp_off"), ptr("entries"), len(host[disp]["entries"]), ptr("qscale"),
+                        ptr("intra"), ptr("repadd"), ptr("mv_fwd"), ptr("mv_bwd"), ptr("mb_dir"), device=True, **slots))
+                else:
+                    pics.append(L.make_picture(
+                        ptype, base + disp, ptr("coef_y"), ptr("coef_cb"), ptr("coef_cr"), ptr("qscale"),
+                        ptr("intra"), ptr("repadd"), ptr("mv_fwd"), ptr("mv_bwd"), ptr("mb_dir"), device=True, **slots))
+        batches.append(dec.batch_create_sparse(pics) if sparse else dec.batch_create(pics))
     torch.cuda.synchronize()
     return batches, keep, host, gop
 
@@ -174,6 +184,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--gops", type=int, default=48, help="independent GOPs per GPU per step")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--boundary", choices=("dense", "sparse"), default="dense",
+                    help="dense: the int16 planes the reference uploads (the BASELINE metric); sparse: the same "
+                         "pictures as per-group entry lists, the output format of the native front end")
     ap.add_argument("--no-rgba", action="store_true", help="leave the RGBA conversion out of the step (diagnostic)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the RGBA conversions on the decoder's second stream (measured: no gain, both kernels want the VALU)")
@@ -213,7 +226,8 @@ def main():
     n_slots = args.gops * GOP_LEN
     dec = L.Decoder(index["coded_w"], index["coded_h"], index["frame_w"], index["frame_h"], n_slots=n_slots,
                     device_id=local_rank, stream=stream.cuda_stream)
-    batches, keep, host, gop = build_workload(L, S, dec, torch, args.gops, seed=0x4C454F4E)
+    sparse = args.boundary == "sparse"
+    batches, keep, host, gop = build_workload(L, S, dec, torch, args.gops, seed=0x4C454F4E, sparse=sparse)
     # display conversion per dependency level (with --overlap on the decoder's second stream)
     levels = S.dependency_levels(gop)
     level_slots = [np.array([g * GOP_LEN + e[1] for g in range(args.gops) for e in lv], dtype=np.int32) for lv in levels]
@@ -270,14 +284,16 @@ def main():
     if rank == 0:
         copy_gbps = dec.measure_copy_bandwidth(1 << 31, 5)
         achieved = recon["algorithmic_bytes"] / (recon["total_ms"] * 1e-3) / 1e9 if recon["total_ms"] else 0.0
-        traffic, traffic_src = pmc_traffic(args.gops)
+        traffic, traffic_src = pmc_traffic(args.gops) if not sparse else (None, None)   # PMC passes exist for the dense boundary
         out = {
             "metric": "1080p macroblocks/s", "value": value, "unit": "macroblocks/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "int32/u8 (fp64 RGBA)",
             "data": "synthetic",
-            "config": {"workload": "1920x1080 IBBP closed GOPs (12 pictures), %d GOPs/GPU/step, dense-int16 boundary "
-                                   "tensors resident in HBM, decode + RGBA of every picture" % args.gops,
+            "config": {"workload": "1920x1080 IBBP closed GOPs (12 pictures), %d GOPs/GPU/step, %s boundary "
+                                   "tensors resident in HBM, decode + RGBA of every picture"
+                                   % (args.gops, "sparse group-list" if sparse else "dense-int16"),
+                       "boundary": args.boundary,
                        "coded": [CW, CH], "gops_per_gpu": args.gops, "pictures_per_step": pics_per_step,
                        "parallelism": "gop-shards x%d" % world, "rgba_in_step": rgba is not None,
                        "rgba_overlapped_on_second_stream": (rgba is not None and args.overlap)},
