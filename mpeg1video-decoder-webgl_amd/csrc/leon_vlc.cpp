@@ -219,12 +219,15 @@ struct leon_vlc_stream {
     std::vector<std::thread> workers;
     std::mutex mu;
     std::condition_variable cv_work, cv_done;
-    uint64_t generation = 0;
-    bool quit = false;
-    int busy = 0;
+    std::atomic<uint64_t> generation{0};
+    std::atomic<bool> quit{false};
+    std::atomic<int> busy{0};
     std::vector<SliceJob> jobs;
     std::atomic<size_t> next_job{0};
-    std::vector<std::vector<uint64_t>> items;  // per thread: (group << 32) | entry
+    // per thread: (group << 32) | entry.  Each list header on its own cache lines: push_back
+    // rewrites the end pointer, and neighbouring headers would ping-pong between cores.
+    struct alignas(128) ItemList { std::vector<uint64_t> v; };
+    std::vector<ItemList> items;
     std::atomic<int> slice_error{0};
     char slice_err_text[160] = "";
     std::mutex err_mu;
@@ -438,24 +441,33 @@ void run_jobs(leon_vlc_stream* s, int tid)
     for (;;) {
         const size_t j = s->next_job.fetch_add(1);
         if (j >= s->jobs.size()) break;
-        decode_slice(s, s->jobs[j], &s->items[(size_t)tid]);
+        decode_slice(s, s->jobs[j], &s->items[(size_t)tid].v);
     }
 }
 
+// Workers spin briefly before they sleep: the slices of a 1080p picture are ~30 us of work
+// each, and a condition-variable wake-up costs about as much as two of them.
 void worker_main(leon_vlc_stream* s, int tid)
 {
     uint64_t seen = 0;
     for (;;) {
-        {
+        int spins = 0;
+        while (s->generation.load(std::memory_order_acquire) == seen && !s->quit.load(std::memory_order_relaxed)) {
+            if (++spins < 4000) {
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+                continue;
+            }
             std::unique_lock<std::mutex> lk(s->mu);
-            s->cv_work.wait(lk, [&] { return s->quit || s->generation != seen; });
-            if (s->quit) return;
-            seen = s->generation;
+            s->cv_work.wait(lk, [&] { return s->quit.load() || s->generation.load() != seen; });
         }
+        if (s->quit.load()) return;
+        seen = s->generation.load(std::memory_order_acquire);
         run_jobs(s, tid);
-        {
+        if (s->busy.fetch_sub(1, std::memory_order_acq_rel) == 1) {
             std::lock_guard<std::mutex> lk(s->mu);
-            if (--s->busy == 0) s->cv_done.notify_one();
+            s->cv_done.notify_one();
         }
     }
 }
@@ -560,20 +572,27 @@ int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
     }
     if (code >= 0) r.pos -= 32;                                    // rewind(32)
 
-    for (auto& v : s->items) v.clear();
+    for (auto& l : s->items) l.v.clear();
     s->next_job.store(0);
     s->slice_error.store(0);
     const int helpers = (int)s->workers.size();
     if (helpers > 0 && s->jobs.size() > 1) {
         {
             std::lock_guard<std::mutex> lk(s->mu);
-            s->busy = helpers;
-            s->generation++;
+            s->busy.store(helpers);
+            s->generation.fetch_add(1, std::memory_order_release);
         }
         s->cv_work.notify_all();
         run_jobs(s, 0);
-        std::unique_lock<std::mutex> lk(s->mu);
-        s->cv_done.wait(lk, [&] { return s->busy == 0; });
+        for (int spins = 0; s->busy.load(std::memory_order_acquire) != 0 && spins < 4000; spins++) {
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (s->busy.load(std::memory_order_acquire) != 0) {
+            std::unique_lock<std::mutex> lk(s->mu);
+            s->cv_done.wait(lk, [&] { return s->busy.load() == 0; });
+        }
     } else {
         run_jobs(s, 0);
     }
@@ -583,9 +602,9 @@ int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
     const size_t ng = (size_t)s->info.n_groups;
     s->grp_off.assign(ng + 1, 0);
     size_t total = 0;
-    for (auto& v : s->items) {
-        total += v.size();
-        for (uint64_t it : v) {
+    for (auto& l : s->items) {
+        total += l.v.size();
+        for (uint64_t it : l.v) {
             const uint32_t g = (uint32_t)(it >> 32);
             if (g < ng) s->grp_off[g + 1]++;
         }
@@ -593,8 +612,8 @@ int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
     for (size_t g = 0; g < ng; g++) s->grp_off[g + 1] += s->grp_off[g];
     s->entries.resize(s->grp_off[ng]);
     s->cursor.assign(s->grp_off.begin(), s->grp_off.end() - 1);
-    for (auto& v : s->items)
-        for (uint64_t it : v) {
+    for (auto& l : s->items)
+        for (uint64_t it : l.v) {
             const uint32_t g = (uint32_t)(it >> 32);
             if (g < ng) s->entries[s->cursor[g]++] = (uint32_t)it;
         }
@@ -690,7 +709,7 @@ void leon_vlc_close(leon_vlc_stream* s)
     if (!s) return;
     {
         std::lock_guard<std::mutex> lk(s->mu);
-        s->quit = true;
+        s->quit.store(true);
     }
     s->cv_work.notify_all();
     for (auto& t : s->workers) t.join();
