@@ -50,7 +50,7 @@ typedef struct leon_vlc_info {
     int32_t coded_width, coded_height;     /* mb_width<<4, mb_height<<4 (jsv.js:364-365) */
     int32_t mb_width, mb_height;
     int32_t groups_y, groups_c, n_groups;
-    int32_t has_alpha;                     /* 'a' flag of the container header (jsv.js:256-259) */
+    int32_t has_alpha;                     /* 'a' flag of the long container header (jsv.js:256-259); -1: short header, no flag */
     double  picture_rate;
     double  duration;                      /* seconds, container header */
     uint32_t keymap_count;                 /* START_MAP entries (jsv.js:264-268) */

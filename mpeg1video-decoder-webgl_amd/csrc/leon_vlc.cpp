@@ -664,6 +664,7 @@ int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_strea
         r.get(16);
         r.get(16);
         double d = r.get(16) / 100.0;
+        s->info.has_alpha = -1;
         if (d == 0) { s->info.has_alpha = (int)r.get(1); d = r.get(23) / 100.0; }
         s->info.duration = d;
         const size_t i = r.pos >> 3;

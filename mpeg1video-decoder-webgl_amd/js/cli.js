@@ -2,16 +2,20 @@
 'use strict';
 /*
  * cli.js -- command-line front end of the Node host side.
- *   node cli.js tensors <stream.jsv>          bitstream layer only: boundary tensors per picture
+ *   node cli.js tensors <stream.jsv> [--seek=<seconds>]
+ *                                             bitstream layer only: boundary tensors per picture
  *                                             (sha256 of each array; small arrays in full) as JSON
  *   node cli.js decode <stream.jsv> [--rgba]  full path through the N-API addon on the GPU:
  *                                             per-frame sha256 of the planes (and RGBA) as JSON
  *   node cli.js seek <stream.jsv> <seconds>   key-map seek, then decode to the end
+ *   ... --native                              parse with the native front end (libleon_vlc) and hand
+ *                                             pictures over as sparse group lists
  */
 const fs = require('fs');
 const crypto = require('crypto');
 const path = require('path');
 const { JsvDecoder } = require('./jsv_decoder');
+const { NativeJsvDecoder } = require('./native_decoder');
 
 const sha = (ta) => (ta ? crypto.createHash('sha256').update(Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength)).digest('hex') : null);
 const b64 = (ta) => (ta ? Buffer.from(ta.buffer, ta.byteOffset, ta.byteLength).toString('base64') : null);
@@ -27,7 +31,8 @@ function main() {
   const bytes = new Uint8Array(fs.readFileSync(file));
   const out = { stream: path.basename(file), events: [], pictures: [] };
   const gpu = cmd !== 'tensors';
-  const dec = new JsvDecoder({ backend: gpu ? loadBackend() : null, keepTensors: !gpu, nSlots: 13 });
+  const Decoder = rest.includes('--native') ? NativeJsvDecoder : JsvDecoder;
+  const dec = new Decoder({ backend: gpu ? loadBackend() : null, keepTensors: !gpu, nSlots: 13 });
   dec.on('meta', (m) => out.events.push(Object.assign({ ev: 'meta' }, m)));
   dec.on('seq', (s) => out.events.push(Object.assign({ ev: 'seq' }, s)));
   dec.on('seeked', (s) => out.events.push(Object.assign({ ev: 'seeked' }, s)));
@@ -52,7 +57,9 @@ function main() {
   });
   dec.addBuffer(bytes);
   dec._initMeta();
-  if (cmd === 'seek') dec.seek(parseFloat(rest[0]));
+  if (cmd === 'seek') dec.seek(parseFloat(rest.filter((a) => !a.startsWith('--'))[0]));
+  const seekOpt = rest.find((a) => a.startsWith('--seek='));
+  if (seekOpt) dec.seek(parseFloat(seekOpt.slice(7)));
   while (dec.decodeFrame());
   out.codedWidth = dec.codedWidth; out.codedHeight = dec.codedHeight; out.mbWidth = dec.mbWidth; out.mbHeight = dec.mbHeight;
   dec.destroy();

@@ -415,16 +415,7 @@ class JsvDecoder extends EventEmitter {
   // ---- the drop-in boundary: jsv.prototype.IDCT_GL (decoders/jsv.js:1177-1336) ---------------
   IDCT_GL() {
     const type = this.pictureCodingType;
-    const pic = {
-      type,
-      coefY: this.currentYDCT16, coefCb: this.currentCbDCT16, coefCr: this.currentCrDCT16,
-      qscale: this.macroblockQuant, intra: this.macroblockIsIntra,
-      repadd: type !== PICTURE_TYPE_I ? this.macroblockRepAdd : null,
-      mvFwd: type !== PICTURE_TYPE_I ? this.macroblockMV : null,
-      mvBwd: type === PICTURE_TYPE_B ? this.macroblockMVBack : null,
-      mbDir: type === PICTURE_TYPE_B ? this.macroblockDir : null,
-      outSlot: -1, refFwdSlot: -1, refBwdSlot: -1,
-    };
+    const pic = this._boundary(type);
     let ts = 0;
     if (this._currentTimeSeqUpdate) { ts = this._currentTimeSeqUpdate; this._currentTimeSeqUpdate = 0; }
     const frame = { ts, type, temporalReference: this.temporalReference, slot: -1, index: this.framesDecoded++ };
@@ -439,7 +430,7 @@ class JsvDecoder extends EventEmitter {
         pic.refBwdSlot = this.anchorNew;
         pic.refFwdSlot = this.anchorOld >= 0 ? this.anchorOld : this.anchorNew;   // closed-GOP leading B pictures
       }
-      this.backend.submitPicture(pic);
+      this._submit(pic);
       if (type !== PICTURE_TYPE_B) {                            // prev_pic_framebuffer = framebuffer (jsv.js:665)
         if (this.anchorOld >= 0) this._drop(this.anchorOld);
         this.anchorOld = this.anchorNew;
@@ -450,6 +441,21 @@ class JsvDecoder extends EventEmitter {
     }
     this.emit('frame', frame);
   }
+
+  // the per-picture arrays IDCT_GL uploads (decoders/jsv.js:1204-1298)
+  _boundary(type) {
+    return {
+      type,
+      coefY: this.currentYDCT16, coefCb: this.currentCbDCT16, coefCr: this.currentCrDCT16,
+      qscale: this.macroblockQuant, intra: this.macroblockIsIntra,
+      repadd: type !== PICTURE_TYPE_I ? this.macroblockRepAdd : null,
+      mvFwd: type !== PICTURE_TYPE_I ? this.macroblockMV : null,
+      mvBwd: type === PICTURE_TYPE_B ? this.macroblockMVBack : null,
+      mbDir: type === PICTURE_TYPE_B ? this.macroblockDir : null,
+      outSlot: -1, refFwdSlot: -1, refBwdSlot: -1,
+    };
+  }
+  _submit(pic) { this.backend.submitPicture(pic); }
 
   _snapshot(pic) {
     const c = (a) => (a ? a.slice() : null);

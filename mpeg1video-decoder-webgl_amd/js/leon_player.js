@@ -18,6 +18,7 @@
 const fs = require('fs');
 const { EventEmitter } = require('events');
 const { JsvDecoder, PICTURE_TYPE_B } = require('./jsv_decoder');
+const { NativeJsvDecoder } = require('./native_decoder');
 
 const NETWORK_EMPTY = 0, NETWORK_IDLE = 1, NETWORK_LOADING = 2, NETWORK_NO_SOURCE = 3;
 const HAVE_NOTHING = 0, HAVE_METADATA = 1, HAVE_CURRENT_DATA = 2, HAVE_FUTURE_DATA = 3, HAVE_ENOUGH_DATA = 4;
@@ -28,10 +29,12 @@ class LeonPlayer extends EventEmitter {
    * opts.backend   the N-API addon module (required to decode pixels; null = bitstream only)
    * opts.realtime  true: one frame per frame duration on a timer (default); false: as fast as possible
    * opts.render    (rgba: Uint8Array, frame) => void, called for every displayed frame when a backend is present
+   * opts.nativeParser  true: parse with libleon_vlc on worker threads and hand pictures over as sparse
+   *                    group lists (native_decoder.js) instead of the JavaScript bitstream layer
    */
   constructor(opts) {
     super();
-    this.opts = Object.assign({ realtime: true, backend: null, render: null, flavour: 0 }, opts || {});
+    this.opts = Object.assign({ realtime: true, backend: null, render: null, flavour: 0, nativeParser: false }, opts || {});
     this.networkState = NETWORK_EMPTY;
     this.readyState = HAVE_NOTHING;
     this.paused = true;
@@ -84,7 +87,8 @@ class LeonPlayer extends EventEmitter {
       this.emit('error', this.error);
       return;
     }
-    const d = this._decoder = new JsvDecoder({ backend: this.opts.backend, nSlots: 13 });
+    const Decoder = this.opts.nativeParser ? NativeJsvDecoder : JsvDecoder;
+    const d = this._decoder = new Decoder({ backend: this.opts.backend, nSlots: 13 });
     d.on('meta', (m) => { this.duration = m.d; });
     d.on('seq', (s) => {
       this.videoWidth = s.w; this.videoHeight = s.h; this.frameDuration = 1000 / s.r;

@@ -8,6 +8,8 @@
 //   h.setQuantMatrices(u8[64], u8[64]); h.acquireSlot(); h.releaseSlot(s); h.freeDecodedSlots();
 //   h.submitPicture({type, outSlot, refFwdSlot, refBwdSlot, coefY, coefCb, coefCr, qscale, intra,
 //                    repadd, mvFwd, mvBwd, mbDir});            // = jsv.prototype.IDCT_GL
+//   h.submitSparse({type, outSlot, refFwdSlot, refBwdSlot, grpOff, entries, nEntries, qscale, intra,
+//                   repadd, mvFwd, mvBwd, mbDir});             // the same through the sparse boundary
 //   h.convertRGBA(slot, flavour) -> Uint8Array; h.readPlanes(slot) -> {y, cb, cr}; h.sync(); h.destroy();
 #include <node_api.h>
 #include <cstdint>
@@ -188,6 +190,45 @@ napi_value SubmitPicture(napi_env env, napi_callback_info info)
     return rc == LEON_OK ? nullptr : throw_leon(env, rc);
 }
 
+// = IDCT_GL with the coefficients as sparse group lists (include/leon_vlc.h): what
+// leon_vlc_napi's nextPicture() returns goes in unchanged
+napi_value SubmitSparse(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    Handle* h = unwrap(env, info, &argc, argv);
+    if (!h) return nullptr;
+    if (argc < 1) {
+        napi_throw_type_error(env, nullptr, "submitSparse(picture)");
+        return nullptr;
+    }
+    napi_value p = argv[0];
+    leon_sparse_picture pic;
+    memset(&pic, 0, sizeof pic);
+    const int mbw = h->cfg.coded_width / 16, mbh = h->cfg.coded_height / 16;
+    const size_t mbs = (size_t)mbw * mbh;
+    const size_t n_groups = (size_t)2 * mbh * ((2 * mbw + 7) / 8) + (size_t)2 * mbh * ((mbw + 7) / 8);
+    int32_t n_entries = 0;
+    bool ok = get_i32(env, p, "type", &pic.type, 0) && get_i32(env, p, "outSlot", &pic.out_slot, -1) &&
+              get_i32(env, p, "refFwdSlot", &pic.ref_fwd_slot, -1) && get_i32(env, p, "refBwdSlot", &pic.ref_bwd_slot, -1) &&
+              get_i32(env, p, "nEntries", &n_entries, 0) && n_entries >= 0 &&
+              get_array(env, p, "grpOff", napi_uint32_array, n_groups + 1, (const void**)&pic.grp_off) &&
+              get_array(env, p, "entries", napi_uint32_array, (size_t)n_entries, (const void**)&pic.entries) &&
+              get_array(env, p, "qscale", napi_uint8_array, mbs, (const void**)&pic.qscale) &&
+              get_array(env, p, "intra", napi_uint8_array, mbs, (const void**)&pic.intra) &&
+              get_array(env, p, "repadd", napi_uint8_array, mbs, (const void**)&pic.repadd) &&
+              get_array(env, p, "mvFwd", napi_int16_array, mbs * 2, (const void**)&pic.mv_fwd) &&
+              get_array(env, p, "mvBwd", napi_int16_array, mbs * 2, (const void**)&pic.mv_bwd) &&
+              get_array(env, p, "mbDir", napi_uint8_array, mbs, (const void**)&pic.mb_dir);
+    if (!ok) {
+        napi_throw_type_error(env, nullptr, "submitSparse: a boundary tensor has the wrong type or is too short");
+        return nullptr;
+    }
+    pic.n_entries = (uint32_t)n_entries;
+    int rc = leon_submit_sparse(h->d, &pic, 1, LEON_MEM_HOST);
+    return rc == LEON_OK ? nullptr : throw_leon(env, rc);
+}
+
 napi_value make_u8(napi_env env, size_t bytes, uint8_t** data)
 {
     napi_value ab, ta;
@@ -294,7 +335,7 @@ napi_value Create(napi_env env, napi_callback_info info)
     NAPI_OK(napi_wrap(env, obj, h, finalize, nullptr, nullptr));
     const struct { const char* name; napi_callback fn; } methods[] = {
         {"setQuantMatrices", SetQuantMatrices}, {"acquireSlot", AcquireSlot}, {"releaseSlot", ReleaseSlot},
-        {"freeDecodedSlots", FreeDecodedSlots}, {"submitPicture", SubmitPicture}, {"convertRGBA", ConvertRGBA},
+        {"freeDecodedSlots", FreeDecodedSlots}, {"submitPicture", SubmitPicture}, {"submitSparse", SubmitSparse}, {"convertRGBA", ConvertRGBA},
         {"readPlanes", ReadPlanes}, {"sync", Sync}, {"destroy", Destroy}};
     for (auto& m : methods) {
         napi_value fn;

@@ -68,6 +68,17 @@ def test_stream_decodes_bit_exact_through_node(name, cw, ch, fw, fh, seed, gopsp
         assert p["rgba"] == _sha(O.ycbcr_to_rgba(y, cb, cr, cw, fw, fh, "cpu")), "RGBA of picture %d" % i
 
 
+@pytest.mark.parametrize("name", ["leon_synth_352x240", "ibbp_96x64", "tiny_ip_32x32"])
+def test_native_front_end_and_sparse_boundary_give_the_same_frames(name):
+    """stream -> libleon_vlc (worker threads) -> submitSparse -> planes / RGBA, under Node,
+    against the JavaScript-parser + dense-boundary path checked above."""
+    a = run_cli("decode", os.path.join(STREAMS, name + ".jsv"), "--rgba")
+    b = run_cli("decode", os.path.join(STREAMS, name + ".jsv"), "--rgba", "--native")
+    assert len(a["pictures"]) == len(b["pictures"]) > 0
+    for i, (x, y) in enumerate(zip(a["pictures"], b["pictures"])):
+        assert (x["type"], x["planes"], x["rgba"]) == (y["type"], y["planes"], y["rgba"]), i
+
+
 def test_ring_exhaustion_throws_like_the_reference():
     """Never releasing frames exhausts the 13-slot ring: Error 'no free render buffers' (jsv.js:1175)."""
     import subprocess

@@ -112,3 +112,25 @@ def test_key_map_seek():
     assert out.returncode == 0, out.stderr
     r = json.loads(out.stdout)
     assert r == {"n": 12, "first": 1, "off": 58896, "count": 2}
+
+
+@pytest.mark.parametrize("name", ["tiny_ip_32x32", "leon_synth_352x240", "ibbp_96x64"])
+def test_native_front_end_under_node_equals_the_javascript_parser(name):
+    """js/native_decoder.js (libleon_vlc through napi/leon_vlc_napi.node, sparse lists densified)
+    against js/jsv_decoder.js: same tensors, same time stamps, same events, picture by picture."""
+    a = run_cli("tensors", os.path.join(STREAMS, name + ".jsv"))
+    b = run_cli("tensors", os.path.join(STREAMS, name + ".jsv"), "--native")
+    assert len(a["pictures"]) == len(b["pictures"]) > 0
+    for i, (x, y) in enumerate(zip(a["pictures"], b["pictures"])):
+        assert (x["type"], x["ts"], x["temporalReference"]) == (y["type"], y["ts"], y["temporalReference"]), i
+        assert x["sha"] == y["sha"], i
+    assert a["events"] == b["events"]
+    assert (a["codedWidth"], a["codedHeight"], a["mbWidth"], a["mbHeight"]) == (b["codedWidth"], b["codedHeight"], b["mbWidth"], b["mbHeight"])
+
+
+def test_native_front_end_seek_equals_the_javascript_parser():
+    a = run_cli("tensors", os.path.join(STREAMS, "leon_synth_352x240.jsv"), "--seek=0.6")
+    b = run_cli("tensors", os.path.join(STREAMS, "leon_synth_352x240.jsv"), "--seek=0.6", "--native")
+    assert [e for e in a["events"] if e["ev"] == "seeked"] == [e for e in b["events"] if e["ev"] == "seeked"] != []
+    assert len(a["pictures"]) == len(b["pictures"]) == 12
+    assert [p["sha"] for p in a["pictures"]] == [p["sha"] for p in b["pictures"]]

@@ -20,7 +20,7 @@ const crypto = require('crypto');
 const backend = %(gpu)s ? require(path.join(%(js)r, '..', 'napi', 'leon_napi.node')) : null;
 const ev = [], shown = [];
 let maxQueue = 0;
-const p = new LeonPlayer({backend, realtime: false,
+const p = new LeonPlayer({backend, realtime: false, nativeParser: %(native)s,
   render: (rgba, f) => shown[shown.length - 1].rgba = crypto.createHash('sha256').update(Buffer.from(rgba.buffer, rgba.byteOffset, rgba.byteLength)).digest('hex')});
 for (const n of ['loadstart','loadedmetadata','loadeddata','canplay','canplaythrough','play','playing','pause','seeking','seeked','ended','error'])
   p.on(n, () => ev.push(n));
@@ -37,8 +37,9 @@ console.log(JSON.stringify({ev, shown, meta, first, maxQueue, canPlay: [p.canPla
 """
 
 
-def _run(stream, gpu, extra=""):
-    src = _SCRIPT % {"js": JSDIR, "gpu": "true" if gpu else "false", "stream": os.path.join(STREAMS, stream), "extra": extra}
+def _run(stream, gpu, extra="", native=False):
+    src = _SCRIPT % {"js": JSDIR, "gpu": "true" if gpu else "false", "stream": os.path.join(STREAMS, stream), "extra": extra,
+                     "native": "true" if native else "false"}
     out = subprocess.run(["node", "-e", src], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     return json.loads(out.stdout)
@@ -55,6 +56,12 @@ def test_events_and_display_order_bitstream_only():
     assert trs == list(range(12)) + list(range(6))
     assert r["maxQueue"] <= 10                      # MAX_DECODED_FRAMES (player/parts/end.js:57)
     assert r["canPlay"] == ["probably", ""]
+
+
+def test_native_parser_option_gives_the_same_playback():
+    a = _run("ibbp_96x64.jsv", gpu=False)
+    b = _run("ibbp_96x64.jsv", gpu=False, native=True)
+    assert a == b
 
 
 def test_seek_restarts_at_the_key_entry():
@@ -74,3 +81,5 @@ def test_player_pixels_match_decode_order_output():
     assert len(r["shown"]) == 18 and r["ev"][-1] == "ended"
     for s in r["shown"]:
         assert s["rgba"] == by_index[s["index"]], s
+    # the same playback with the native front end and the sparse boundary
+    assert _run("ibbp_96x64.jsv", gpu=True, native=True)["shown"] == r["shown"]
