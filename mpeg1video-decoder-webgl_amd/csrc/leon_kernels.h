@@ -282,7 +282,7 @@ __device__ __forceinline__ int dequant_any(int X, int qO, int pm, int nim, int l
     int z;
     asm("v_med3_i32 %0, %1, 0, 1" : "=v"(z) : "v"(f));   // inline constants: no registers for 0 and 1
     f = (f - z) | (sg & 1);
-    f = med3_asm(f, lo2048, hi2047);
+    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(f) : "v"(f), "s"(lo2048), "v"(hi2047));   // one scalar operand is free
     return __mul24(f, pm);
 }
 
@@ -515,15 +515,14 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         }
     }
     const v2u msel = ia ? mI : mN;
-    uint32_t qow[8];                                  // quantiser_scale * Q[i][c], < 2^13
-#pragma unroll
-    for (int i = 0; i < 8; i++) qow[i] = __umul24((uint32_t)q, ((i < 4 ? msel.x : msel.y) >> (8 * (i & 3))) & 255u);
+    uint32_t qv = (uint32_t)q;
     int nim = ia ? 0 : -1;
     asm("" : "+v"(nim));                              // keep it a mask (v_and), not a select
-    // the clamp bounds live in two registers for the whole task (v_med3 takes no literals on
-    // gfx950, and the compiler would otherwise re-materialise them in front of every use)
+    // the clamp bounds live in registers for the whole task (v_med3 takes no literals on gfx950, and
+    // the compiler would otherwise re-materialise them in front of every use): one scalar, one vector
+    // -- a VOP3 instruction may read one scalar register
     int lo2048 = -2048, hi2047 = 2047;
-    asm("" : "+v"(lo2048), "+v"(hi2047));
+    asm("" : "+s"(lo2048), "+v"(hi2047));
     const bool dc_lane = c == 0 && ia;
     char* const lds_wr = lds + hi3 * 128 + lo3 * 16;
     const char* const lds_col = lds + b * 16 + c * 2;
@@ -596,6 +595,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             const int cols_live = 8 - (__builtin_clzll(colbits | 1ull) >> 3);
             // ---- stage 2: column pass ------------------------------------------------------
             const int dc = X[0];
+            asm volatile("" : "+v"(qv));                  // do not share the products between the halves
             int rows_live = 1;                            // wave-uniform: 1 + highest row with a non-zero
 #pragma unroll
             for (int i = 0; i < 8; i++) {
@@ -604,7 +604,10 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
                 if (nz[i] != 0) {
                     rows_live = i + 1;
                     int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
-                    X[i] = dequant_any(X[i], (int)qow[i], P, nim, lo2048, hi2047);
+                    // quantiser_scale * Q[i][c] (< 2^13) is formed where it is used: eight products kept
+                    // across both halves would cost the B path a wave of occupancy
+                    const int qO = (int)__umul24(qv, ((i < 4 ? msel.x : msel.y) >> (8 * (i & 3))) & 255u);
+                    X[i] = dequant_any(X[i], qO, P, nim, lo2048, hi2047);
                 }
             }
             if (dc_lane) X[0] = dc * 256;                 // COL_4 / COL_INT_31
