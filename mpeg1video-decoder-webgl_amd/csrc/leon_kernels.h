@@ -406,13 +406,20 @@ __device__ __forceinline__ void gather9_slow(const LEON_GLOBAL uint8_t* ref, uin
 // the ninth row of a block is fetched by its n == 7 lanes alone (all other lanes carry the
 // out-of-range offset, which costs no cache access), and finish_rows() moves the rest
 // between lanes.  That halves the L1 accesses of the reference fetch.
+__device__ __forceinline__ int clamp_med3(int v, int hi)      // min(max(v, 0), hi) in one instruction
+{
+    int d;
+    asm("v_med3_i32 %0, %1, 0, %2" : "=v"(d) : "v"(v), "s"(hi));
+    return d;
+}
+
 __device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, int W, int H, int y,
                                               int px, int ay, int oh, int ov, bool in_pic, bool last_row)
 {
-    int py0 = min(max(y + ay, 0), H - 1);
-    int py1 = min(max(y + ay + ov, 0), H - 1);
-    uint32_t r0 = (uint32_t)__mul24(py0, W);
-    uint32_t r1 = (uint32_t)__mul24(py1, W);
+    const int yy = y + ay;
+    const uint32_t r0 = (uint32_t)__mul24(clamp_med3(yy, H - 1), W);
+    // the row below: one line further unless the clamp holds both rows on the same edge line
+    const uint32_t r1 = r0 + ((uint32_t)yy < (uint32_t)(H - 1) ? (uint32_t)W : 0u);
     RefRows R;
     R.oh = (uint32_t)oh;
     R.m0 = R.m1 = R.m2 = 0;
@@ -422,7 +429,7 @@ __device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, in
         // buffer loads: wave-uniform descriptor in SGPRs + 32-bit offset, no 64-bit address math
         const __amdgpu_buffer_rsrc_t rs = buf_rsrc((const void*)ref);
         const v3u a = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(r0 + xo), 0, 0);
-        const v3u c = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)((r1 + xo) | (last_row && ov ? 0u : kOobBit)), 0, 0);
+        const v3u c = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(last_row && ov ? r1 + xo : kOobBit), 0, 0);
         R.l0 = a.x; R.l1 = a.y; R.l2 = a.z;
         R.m0 = c.x; R.m1 = c.y; R.m2 = c.z;
     } else {                                         // vector leaves the picture (rare)
@@ -544,13 +551,10 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     bool inA = true, inB = true, usef = true, useb = true;
     if (TYPE != 1) {
         nopred = ldg<uint8_t>(gptr(pd.repadd), mb) >= 128;    // .r > 0.5
-        const uint32_t mf = ldg<uint32_t>(gptr(pd.mv_fwd), mb * 4);
-        int fh = (int)(short)(mf & 0xffff), fv = (int)mf >> 16;
-        int bh = 0, bv = 0;
+        uint32_t mf = ldg<uint32_t>(gptr(pd.mv_fwd), mb * 4);
+        uint32_t mk = 0;
         if (TYPE == 3) {
-            const uint32_t mk = ldg<uint32_t>(gptr(pd.mv_bwd), mb * 4);
-            bh = (int)(short)(mk & 0xffff);
-            bv = (int)mk >> 16;
+            mk = ldg<uint32_t>(gptr(pd.mv_bwd), mb * 4);
             const int dir = ldg<uint8_t>(gptr(pd.mb_dir), mb) & 3;
             usef = (dir & 1) != 0;
             useb = (dir & 2) != 0;
@@ -558,18 +562,20 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             // predictor A always reads the forward reference, B the backward one (scalar bases,
             // 32-bit offsets); an unused direction fetches with a zero vector and is replaced by
             // the other predictor afterwards: (p + p + 1) >> 1 == p
-            if (!usef) { fh = 0; fv = 0; }
-            if (!useb) { bh = 0; bv = 0; }
+            if (!usef) mf = 0;                                // both components at once
+            if (!useb) mk = 0;
         }
+        const int fh = (int)(short)(mf & 0xffff), fv = (int)mf >> 16;
+        const int bh = (int)(short)(mk & 0xffff), bv = (int)mk >> 16;
         {   // chroma: vector truncated toward zero first (mv_coef 0.5), then floor / parity
             int h = CHROMA ? fh / 2 : fh, v = CHROMA ? fv / 2 : fv;
             pxA = x0 + (h >> 1); ohA = h & 1; ayA = v >> 1; ovA = v & 1;
-            inA = pxA >= 0 && pxA + 7 + ohA <= W - 1;
+            inA = (uint32_t)pxA < (uint32_t)(W - 7 - ohA);    // 0 <= px && px + 7 + oh <= W - 1 (W >= 8)
         }
         if (TYPE == 3) {
             int h = CHROMA ? bh / 2 : bh, v = CHROMA ? bv / 2 : bv;
             pxB = x0 + (h >> 1); ohB = h & 1; ayB = v >> 1; ovB = v & 1;
-            inB = pxB >= 0 && pxB + 7 + ohB <= W - 1;
+            inB = (uint32_t)pxB < (uint32_t)(W - 7 - ohB);
         }
     }
     const v2u msel = ia ? mI : mN;
