@@ -89,6 +89,7 @@ AnyPic any_of(const leon_sparse_picture& q)
 
 struct Staging {                 // device copy of one host-submitted picture
     char* base = nullptr;
+    char* host = nullptr;        // pinned mirror: the caller's arrays are gathered here, then ONE async copy
     hipEvent_t done = nullptr;
     bool busy = false;
 };
@@ -406,6 +407,7 @@ void leon_destroy(leon_decoder* d)
     for (auto e : d->ev_pool) hipEventDestroy(e);
     for (auto& s : d->stages) {
         if (s.base) hipFree(s.base);
+        if (s.host) hipHostFree(s.host);
         if (s.done) hipEventDestroy(s.done);
     }
     if (d->d_slots) hipFree(d->d_slots);
@@ -491,6 +493,7 @@ int submit_picture_any(leon_decoder* d, const AnyPic& pic)
     d->next_stage = (d->next_stage + 1) % leon_decoder::kStages;
     if (!s.base) {
         HIP_TRY(hipMalloc(&s.base, d->stage_bytes));
+        HIP_TRY(hipHostMalloc((void**)&s.host, d->stage_bytes, hipHostMallocDefault));
         HIP_TRY(hipEventCreateWithFlags(&s.done, hipEventDisableTiming));
     }
     if (s.busy) HIP_TRY(hipEventSynchronize(s.done));
@@ -498,10 +501,13 @@ int submit_picture_any(leon_decoder* d, const AnyPic& pic)
     size_t mpad = (mbs + 255) / 256 * 256, vpad = (mbs * 4 + 255) / 256 * 256;
     char* p = s.base;
     AnyPic dp = pic;
+    // The pieces are gathered into the pinned mirror with plain memcpy and cross PCIe in one
+    // asynchronous copy: the caller gets its arrays (and its thread) back after the gather, where
+    // nine copies from pageable memory would each block until staged by the runtime.
     auto put = [&](const void* src, size_t bytes, size_t reserve) -> const void* {
         char* at = p;
         p += reserve;
-        if (src && bytes) hipMemcpyAsync(at, src, bytes, hipMemcpyHostToDevice, d->stream);
+        if (src && bytes) memcpy(s.host + (at - s.base), src, bytes);
         return src ? at : nullptr;
     };
     auto pad256 = [](size_t v) { return (v + 255) / 256 * 256; };
@@ -521,7 +527,7 @@ int submit_picture_any(leon_decoder* d, const AnyPic& pic)
     dp.p.mb_dir = (const uint8_t*)put(type == LEON_PIC_B ? pic.p.mb_dir : nullptr, mbs, mpad);
     dp.p.mv_fwd = (const int16_t*)put(type != LEON_PIC_I ? pic.p.mv_fwd : nullptr, mbs * 4, vpad);
     dp.p.mv_bwd = (const int16_t*)put(type == LEON_PIC_B ? pic.p.mv_bwd : nullptr, mbs * 4, vpad);
-    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(s.base, s.host, (size_t)(p - s.base), hipMemcpyHostToDevice, d->stream));
     int at = 0;
     rc = reserve_descs(d, 1, at);
     if (rc != LEON_OK) return rc;
