@@ -16,21 +16,24 @@
 //                           CLAMP_TO_EDGE of jsv.js:216-217
 //   colour conversion       player/easybits.player.js:2674-2785, player/parts/end.js:77-156
 //
-// Work decomposition of k_recon: one 64-lane wave = one "block group" = 8
-// horizontally adjacent 8x8 blocks of one plane (64 x 8 samples).  Waves never
-// talk to each other (no __syncthreads); each owns a private LDS strip.
-//   stage 0  every global load of the group is issued up front: the coefficient row
-//            segment (16 B/lane; each load instruction covers 8 full 128-B lines),
-//            the per-macroblock maps, and -- as soon as the vectors are there -- the
-//            reference rows (3 aligned dwords per row), so HBM latency overlaps the IDCT
+// Work decomposition of k_recon: one 64-lane wave = one task = TWO "block groups" that share
+// their macroblocks (luma: the upper and lower 64x8 halves of four macroblocks; chroma: the Cb
+// and the Cr group of one block row); a group = 8 horizontally adjacent 8x8 blocks.  Waves never
+// talk to each other (no __syncthreads); each owns a private LDS strip.  One kernel instance
+// per picture type and boundary format (k_recon<type, sparse>).
+//   prologue every load that does not depend on the macroblock maps is requested first (first
+//            coefficient rows or entry runs, matrix columns), then the maps and vectors; when
+//            those arrive, the reference rows of BOTH halves (one aligned 12-byte row per lane)
 //   stage 1  lane (r,b): coefficient row r of block b -> LDS tile [r][b][c]
-//   stage 2  lane (b,c): column c of block b: 8 LDS reads, dequant (rows whose 64
-//            coefficients are all zero are skipped wave-uniformly, exactly like the
-//            shader's `if (X == 0.) continue`), butterfly, floor(v*0.4f), int16
-//            hand-off wrap, trunc(5w/2), written transposed to LDS as int32
-//   stage 3  lane (b,n): row n of block b: two 16-byte LDS reads, butterfly
-//   stage 4  lane (b,n): 8 predicted samples via v_alignbyte + v_lerp_u8, add the
-//            residual, saturate-pack (v_ashr_pk_u8_i32), one 8-byte store
+//            (sparse boundary: the tile is cleared and the group's entries are scattered into it)
+//   stage 2  lane (c = lane>>3, b = lane&7): column c of block b: 8 LDS reads, branch-free dequant
+//            of the rows that are live anywhere in the wave (scalar liveness masks; zeros stay
+//            zero like the shader's `if (X == 0.) continue`), butterfly, floor(v*0.4f), int16
+//            hand-off wrap on a rare path, trunc(5w/2), written transposed to LDS as int32
+//   stage 3  lane (n = lane>>3, b = lane&7): row n of block b: two 16-byte LDS reads, butterfly
+//   stage 4  same lanes: the 8 lanes of a group hold 64 contiguous samples of ONE picture row, so
+//            reference fetches and stores coalesce; lower reference row from lane+8; 8 predicted
+//            samples via v_alignbyte + v_lerp_u8, residual add, v_ashr_pk_u8_i32, one 8-byte store
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
