@@ -91,6 +91,7 @@ const uint8_t kDefaultIntra[64] = {
 
 struct Tables {
     Lookup mba, mbtype[4], cbp, motion, dc_lum, dc_chr, coef;
+    int32_t coef8[256];          // the coefficient codes of at most 8 bits (most of them): 1 KB, stays in L1
     Tables()
     {
         mba.init(11);
@@ -131,6 +132,10 @@ struct Tables {
         for (int i = 1; i < 111; i++) coef.add((runs[i] << 8) | levels[i], kCoef[i].code, kCoef[i].len);
         coef.add(0x0001, 0x1, 1);
         coef.add(0xffff, 0x1, 6);
+        for (int i = 0; i < 256; i++) {
+            const int32_t e = coef.t[(size_t)i << 8];
+            coef8[i] = (e != 0 && (e >> 16) <= 8) ? e : 0;
+        }
     }
 };
 const Tables& tables()
@@ -143,7 +148,7 @@ const Tables& tables()
 
 struct Bits {
     const uint8_t* b = nullptr;
-    size_t nbytes = 0;           // real length (the buffer has 8 readable bytes more)
+    size_t nbytes = 0;           // real length (the buffer has 16 readable bytes more)
     size_t pos = 0;              // in bits
     bool bad = false;
 
@@ -300,7 +305,7 @@ bool decode_block(SliceCtx& c, int block)
     }
     const uint64_t ghi = (uint64_t)gid << 32;
     const uint32_t boff = (bq * 16u) << 16;
-    int n = 0;
+    int n = 0, c_dc_pending = 0;
     if (c.mb_intra) {
         int predictor, size;
         if (block < 4) { predictor = c.dc_y; size = r.vlc(T.dc_lum); }
@@ -312,31 +317,60 @@ bool decode_block(SliceCtx& c, int block)
                                                     : predictor + ((int)(0xffffffffu << size) | (differential + 1));
         }
         if (block < 4) c.dc_y = dc; else if (block == 4) c.dc_cr = dc; else c.dc_cb = dc;
-        if ((int16_t)dc != 0) c.out->push_back(ghi | boff | (uint16_t)(int16_t)dc);
+        c_dc_pending = dc;
         n = 1;
     }
+    // The coefficient loop works on a 64-bit window of the stream (>= 57 valid bits; one symbol takes
+    // at most 28) and reads code, sign and escape fields out of it with shifts: one table lookup and
+    // one position update per coefficient.  Same decisions as the reference's loop, jsv.js:1396-1443.
+    const uint8_t* const bytes = r.b;
+    const size_t end_bits = r.nbytes * 8;
+    size_t pos = r.pos;
+    uint64_t tmp[64];
+    int k = 0;
+    if (c.mb_intra && (int16_t)c_dc_pending != 0) tmp[k++] = ghi | boff | (uint16_t)(int16_t)c_dc_pending;
     for (;;) {
+        if (pos >= end_bits) { r.pos = pos; r.bad = true; c.err = "bitstream ends inside a block"; return false; }
+        uint64_t w;
+        memcpy(&w, bytes + (pos >> 3), 8);
+        w = __builtin_bswap64(w) << (pos & 7);
+        int32_t e = T.coef8[w >> 56];
+        if (e == 0) {
+            e = T.coef.t[w >> 48];
+            if (e == 0) { r.pos = pos; r.bad = true; c.err = "invalid coefficient code"; return false; }
+        }
+        const int len = e >> 16, coeff = e & 0xffff;
         int run, level;
-        const int coeff = r.vlc(T.coef);
-        if (r.bad) { c.err = "invalid coefficient code"; return false; }
-        if (coeff == 0x0001 && n > 0 && r.get(1) == 0) break;          // '10' = end of block
-        if (coeff == 0xffff) {
-            run = (int)r.get(6);
-            level = (int)r.get(8);
-            if (level == 0) level = (int)r.get(8);
-            else if (level == 128) level = (int)r.get(8) - 256;
+        if (coeff == 0x0001) {                               // the one-bit code '1'
+            if (n > 0) {
+                if (((w >> 62) & 1) == 0) { pos += 2; break; }          // '10' = end of block
+                level = ((w >> 61) & 1) ? -1 : 1;                       // '11' + sign
+                pos += 3;
+            } else {
+                level = ((w >> 62) & 1) ? -1 : 1;                       // first coefficient: '1' + sign
+                pos += 2;
+            }
+            run = 0;
+        } else if (coeff == 0xffff) {                        // escape: 6-bit run, 8- or 16-bit level
+            run = (int)((w >> 52) & 63);
+            level = (int)((w >> 44) & 255);
+            pos += 20;
+            if (level == 0) { level = (int)((w >> 36) & 255); pos += 8; }
+            else if (level == 128) { level = (int)((w >> 36) & 255) - 256; pos += 8; }
             else if (level > 128) level -= 256;
         } else {
             run = coeff >> 8;
             level = coeff & 0xff;
-            if (r.get(1)) level = -level;
+            if ((w >> (63 - len)) & 1) level = -level;
+            pos += (size_t)len + 1;
         }
         n += run;
-        if (n > 63) { c.err = "coefficient index overflow"; return false; }
+        if (n > 63) { r.pos = pos; c.err = "coefficient index overflow"; return false; }
         const uint32_t z = kZigZag[n++];
-        if (level != 0)
-            c.out->push_back(ghi | boff | (((z >> 3) * 128u + (z & 7u) * 2u) << 16) | (uint16_t)(int16_t)level);
+        if (level != 0) tmp[k++] = ghi | boff | (((z >> 3) * 128u + (z & 7u) * 2u) << 16) | (uint16_t)(int16_t)level;
     }
+    r.pos = pos;
+    c.out->insert(c.out->end(), tmp, tmp + k);
     return !r.bad;
 }
 
@@ -651,7 +685,7 @@ int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_strea
     leon_vlc_stream* s = new (std::nothrow) leon_vlc_stream();
     if (!s) return fail(LEON_VLC_ERR_NOMEM, "out of memory");
     s->data.assign(data, data + n);
-    s->data.resize(n + 8, 0);
+    s->data.resize(n + 16, 0);
     s->r.b = s->data.data();
     s->r.nbytes = n;
     s->r.pos = 0;
