@@ -188,6 +188,8 @@ def main():
                     help="dense: the int16 planes the reference uploads (the BASELINE metric); sparse: the same "
                          "pictures as per-group entry lists, the output format of the native front end")
     ap.add_argument("--no-rgba", action="store_true", help="leave the RGBA conversion out of the step (diagnostic)")
+    ap.add_argument("--rgba-lag", type=int, default=0,
+                    help="issue the RGBA conversion of a dependency level this many levels late (0 = right after it)")
     ap.add_argument("--overlap", action="store_true",
                     help="run the RGBA conversions on the decoder's second stream (measured: no gain, both kernels want the VALU)")
     args = ap.parse_args()
@@ -236,10 +238,19 @@ def main():
     if args.overlap:
         dec.set_overlap_convert(True)
 
+    defer = 0 if args.rgba_lag is None else args.rgba_lag
+
     def step():
+        # --rgba-lag N issues the display conversion of level k N levels late, so that the next
+        # level's reconstruction reads its references before 1.2 GB of RGBA output per level
+        # passes through the caches.  Measured: no difference (the anchors are re-fetched from
+        # HBM either way at 48 GOPs per launch); default 0 = convert right after the level.
         for k, b in enumerate(batches):
             dec.batch_run(b)
-            if rgba_lv is not None:
+            if rgba_lv is not None and k >= defer:
+                dec.convert_rgba_batch(level_slots[k - defer], rgba_lv[k - defer].data_ptr())
+        if rgba_lv is not None:
+            for k in range(len(batches) - defer, len(batches)):
                 dec.convert_rgba_batch(level_slots[k], rgba_lv[k].data_ptr())
 
     def fence():

@@ -275,13 +275,15 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
 // descriptors sorted by type ([I..][P..][B..]); one launch per type present
 int launch_recon(leon_decoder* d, const PicDesc* d_descs, const int count[3], bool sparse = false, const uint64_t* entries = nullptr)
 {
-    int at = 0;
-    for (int k = 0; k < 3; k++) {
+    // B pictures first, anchors last: what the NEXT batch will read as references (I and P planes)
+    // is then the most recently written data and still sits in the 256 MB Infinity Cache / L2,
+    // instead of being pushed out by B planes nobody reads again.
+    const int at[3] = {0, count[0], count[0] + count[1]};
+    for (int k = 2; k >= 0; k--) {
         if (count[k] > 0) {
-            int rc = launch_recon_type(d, k + 1, d_descs + at, count[k], sparse, entries ? entries[k] : 0);
+            int rc = launch_recon_type(d, k + 1, d_descs + at[k], count[k], sparse, entries ? entries[k] : 0);
             if (rc != LEON_OK) return rc;
         }
-        at += count[k];
     }
     return LEON_OK;
 }

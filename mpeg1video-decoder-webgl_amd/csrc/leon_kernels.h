@@ -895,12 +895,16 @@ __global__ __launch_bounds__(256) void k_rgba_twin8(const uint8_t* __restrict__ 
             o1[px] = u8_clamped(r + yb) | (u8_clamped(g + yb) << 8) | (u8_clamped(b + yb) << 16) | 0xff000000u;
         }
     }
-    uint8_t* d0 = rgba + ((size_t)f * G.fw * G.fh + (size_t)(2 * row) * G.fw + 8 * col8) * 4;
-    uint8_t* d1 = d0 + (size_t)G.fw * 4;
-    reinterpret_cast<uint4*>(d0)[0] = make_uint4(o0[0], o0[1], o0[2], o0[3]);
-    reinterpret_cast<uint4*>(d0)[1] = make_uint4(o0[4], o0[5], o0[6], o0[7]);
-    reinterpret_cast<uint4*>(d1)[0] = make_uint4(o1[0], o1[1], o1[2], o1[3]);
-    reinterpret_cast<uint4*>(d1)[1] = make_uint4(o1[4], o1[5], o1[6], o1[7]);
+    // one frame = one buffer resource (wave-uniform base), 32-bit offsets inside it.  Default cache
+    // policy: nt / sc1 on these stores make THIS kernel 25-70 % slower (measured), although the
+    // reconstruction launches that follow gain 3-6 % from the cleaner L2.
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(rgba + (size_t)f * G.fw * G.fh * 4);
+    const uint32_t o = ((uint32_t)(2 * row) * (uint32_t)G.fw + 8u * (uint32_t)col8) * 4u;
+    const uint32_t o1r = o + (uint32_t)G.fw * 4u;
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{o0[0], o0[1], o0[2], o0[3]}, rs, (int)o, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{o0[4], o0[5], o0[6], o0[7]}, rs, (int)(o + 16u), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{o1[0], o1[1], o1[2], o1[3]}, rs, (int)o1r, 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{o1[4], o1[5], o1[6], o1[7]}, rs, (int)(o1r + 16u), 0, 0);
 }
 
 // fills what the quad loop never writes (odd last row / column, drift leftovers) with 255
