@@ -732,8 +732,8 @@ int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, vo
             size_t nd = (size_t)G.fw * G.fh * n;
             hipLaunchKernelGGL(k_fill255, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, cs, (uint32_t*)rgba_device, nd);
         }
-        if (G.cols > 0 && G.rows > 0 && (G.fw & 7) == 0 && ((size_t)rgba_device & 15) == 0)
-            hipLaunchKernelGGL(k_rgba_twin8, dim3((G.fw / 8 + 63) / 64, G.rows, n), dim3(64), 0, cs,
+        if (G.cols > 0 && G.rows > 0 && (G.fw & 3) == 0 && ((size_t)rgba_device & 15) == 0)
+            hipLaunchKernelGGL(k_rgba_twin4, dim3((G.fw / 4 + 255) / 256, G.rows, n), dim3(256), 0, cs,
                                d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
         else if (G.cols > 0 && G.rows > 0)
             hipLaunchKernelGGL(k_rgba_twin, dim3((G.cols + 255) / 256, G.rows, n), dim3(256), 0, cs,

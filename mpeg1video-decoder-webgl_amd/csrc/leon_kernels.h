@@ -858,53 +858,46 @@ __global__ __launch_bounds__(256) void k_rgba_twin(const uint8_t* __restrict__ s
     *reinterpret_cast<uint32_t*>(dst + d2 + 4) = px[3];
 }
 
-// Fast path of the CPU twin for frame widths that are a multiple of 8 (no index drift, whole
-// 16-byte stores): one thread = 8 x 2 pixels = four 2x2 quads; same fp64 operations in the same
-// order as k_rgba_twin.
-__global__ __launch_bounds__(256) void k_rgba_twin8(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
+// Fast path of the CPU twin for frame widths that are a multiple of 4 (no index drift): one thread =
+// 4 x 2 pixels = two 2x2 quads, same fp64 operations in the same order as k_rgba_twin.  The 64 lanes
+// of a wave store 1 KB of contiguous RGBA per row with one 16-byte store each -- 5.8 TB/s; the
+// 8 x 2 form (two 16-byte stores per lane and row, lanes 32 bytes apart) reached 5.4.
+__global__ __launch_bounds__(256) void k_rgba_twin4(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
                                                     uint8_t* __restrict__ rgba, RgbaGeom G)
 {
-    const int col8 = blockIdx.x * blockDim.x + threadIdx.x;     // group of 8 columns
+    const int col4 = blockIdx.x * blockDim.x + threadIdx.x;     // group of 4 columns
     const int row = blockIdx.y;                                 // row pair
     const int f = blockIdx.z;
-    if (col8 * 8 >= G.fw) return;
+    if (col4 * 4 >= G.fw) return;
     const size_t stride = ((size_t)G.slot_stride_hi << 32) | G.slot_stride_lo;
     const uint8_t* Y = slots + (size_t)slot_ids[f] * stride;
     const uint8_t* Cb = Y + (size_t)G.cw * G.ch;
     const uint8_t* Cr = Cb + ((size_t)G.cw * G.ch >> 2);
     const int hw = G.cw >> 1;
-    // read once: non-temporal
-    const v2u y0 = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(Y + (size_t)(2 * row) * G.cw + 8 * col8));
-    const v2u y1 = __builtin_nontemporal_load(reinterpret_cast<const v2u*>(Y + (size_t)(2 * row + 1) * G.cw + 8 * col8));
-    const uint32_t cb4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(Cb + (size_t)row * hw + 4 * col8));
-    const uint32_t cr4 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(Cr + (size_t)row * hw + 4 * col8));
-    uint32_t o0[8], o1[8];
-    const uint32_t yy0[2] = {y0.x, y0.y}, yy1[2] = {y1.x, y1.y};
+    const uint32_t y0 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(Y + (size_t)(2 * row) * G.cw + 4 * col4));
+    const uint32_t y1 = __builtin_nontemporal_load(reinterpret_cast<const uint32_t*>(Y + (size_t)(2 * row + 1) * G.cw + 4 * col4));
+    const uint32_t cb2 = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(Cb + (size_t)row * hw + 2 * col4));
+    const uint32_t cr2 = __builtin_nontemporal_load(reinterpret_cast<const uint16_t*>(Cr + (size_t)row * hw + 2 * col4));
+    uint32_t o0[4], o1[4];
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-        const double yuvr = (double)((cr4 >> (8 * q)) & 255u) - 128.0, yuvb = (double)((cb4 >> (8 * q)) & 255u) - 128.0;
+    for (int q = 0; q < 2; q++) {
+        const double yuvr = (double)((cr2 >> (8 * q)) & 255u) - 128.0, yuvb = (double)((cb2 >> (8 * q)) & 255u) - 128.0;
         const double r = yuvr * 1.59603;
         const double g = (-0.81297 * yuvr) - (0.39176 * yuvb);
         const double b = yuvb * 2.01723;
 #pragma unroll
         for (int k = 0; k < 2; k++) {
             const int px = 2 * q + k;
-            const double ya = ((double)((yy0[px >> 2] >> (8 * (px & 3))) & 255u) - 16.0) * 1.16438;
-            const double yb = ((double)((yy1[px >> 2] >> (8 * (px & 3))) & 255u) - 16.0) * 1.16438;
+            const double ya = ((double)((y0 >> (8 * px)) & 255u) - 16.0) * 1.16438;
+            const double yb = ((double)((y1 >> (8 * px)) & 255u) - 16.0) * 1.16438;
             o0[px] = u8_clamped(r + ya) | (u8_clamped(g + ya) << 8) | (u8_clamped(b + ya) << 16) | 0xff000000u;
             o1[px] = u8_clamped(r + yb) | (u8_clamped(g + yb) << 8) | (u8_clamped(b + yb) << 16) | 0xff000000u;
         }
     }
-    // one frame = one buffer resource (wave-uniform base), 32-bit offsets inside it.  Default cache
-    // policy: nt / sc1 on these stores make THIS kernel 25-70 % slower (measured), although the
-    // reconstruction launches that follow gain 3-6 % from the cleaner L2.
     const __amdgpu_buffer_rsrc_t rs = buf_rsrc(rgba + (size_t)f * G.fw * G.fh * 4);
-    const uint32_t o = ((uint32_t)(2 * row) * (uint32_t)G.fw + 8u * (uint32_t)col8) * 4u;
-    const uint32_t o1r = o + (uint32_t)G.fw * 4u;
+    const uint32_t o = ((uint32_t)(2 * row) * (uint32_t)G.fw + 4u * (uint32_t)col4) * 4u;
     __builtin_amdgcn_raw_buffer_store_b128(v4u{o0[0], o0[1], o0[2], o0[3]}, rs, (int)o, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(v4u{o0[4], o0[5], o0[6], o0[7]}, rs, (int)(o + 16u), 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(v4u{o1[0], o1[1], o1[2], o1[3]}, rs, (int)o1r, 0, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(v4u{o1[4], o1[5], o1[6], o1[7]}, rs, (int)(o1r + 16u), 0, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(v4u{o1[0], o1[1], o1[2], o1[3]}, rs, (int)(o + (uint32_t)G.fw * 4u), 0, 0);
 }
 
 // fills what the quad loop never writes (odd last row / column, drift leftovers) with 255
