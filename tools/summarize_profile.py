@@ -30,7 +30,7 @@ def main():
             with open(os.path.join(out, a.tag + "_kernel_trace_leon.csv"), "w") as w:
                 w.write("kernel,grid_x,duration_us\n")
                 for r in rows:
-                    w.write("%s,%s,%.3f\n" % (r["Kernel_Name"].split("(")[0], r["Grid_Size_X"],
+                    w.write('"%s",%s,%.3f\n' % (r["Kernel_Name"].split("(")[0], r["Grid_Size_X"],
                                               (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     pmc = collections.defaultdict(dict)
     for d in a.pmc:
