@@ -22,6 +22,11 @@
  *   mv_bwd,mb_dir B pictures only (beyond the reference, ISO 11172-2 2.4.4.3):
  *                 backward vectors, and per-MB direction bits 1=fwd 2=bwd
  * Arithmetic domain: |level| <= 32767, qscale 0..31, matrix entries 0..255.
+ *
+ * Threading: the calls on ONE decoder must be serialised by the caller (the reference drives its
+ * GL context from one thread, decoders/jsv.js:427-430); different decoders are independent and may
+ * be used from different threads.  Everything a decoder launches is ordered on its HIP stream;
+ * submits return as soon as the work is queued.
  */
 #ifndef LEON_H
 #define LEON_H

@@ -25,6 +25,9 @@
  *     bits  0..15  level (int16; intra DC in the 0..255 predictor domain, jsv.js:1346-1443)
  *     bits 16..25  byte offset of the coefficient in the group's int16 tile [row r][block b][col c]
  *                  = r*128 + b*16 + c*2   (r, c natural order inside the block; b = block in group)
+ *
+ * Threading: one stream is driven from one thread at a time (it owns its worker threads);
+ * different streams are independent -- one per GOP shard is how the front end scales across cores.
  */
 #ifndef LEON_VLC_H
 #define LEON_VLC_H
