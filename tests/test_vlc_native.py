@@ -177,3 +177,42 @@ def test_damaged_streams_fail_cleanly():
                     break
             except V.VlcError:
                 pass                      # an error is reported per picture; the parser moves on
+
+
+@pytest.mark.skipif(shutil.which("node") is None, reason="node is not installed")
+@pytest.mark.parametrize("slice_mbs", [1, 4, 5, 16])
+def test_slices_that_start_mid_row_and_span_rows(slice_mbs, tmp_path):
+    """MPEG-1 slices need not be macroblock rows.  Streams whose slices are 1, 4, 5 or 16 macroblocks
+    long (6 per row: mid-row starts, row-spanning slices) through the JavaScript mirror (serial slice
+    loop of the reference) and through the native parser with 1 and 8 threads: same tensors."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import jsv_writer as W
+    import synth as S
+    rng = np.random.default_rng(100 + slice_mbs)
+    cw, ch = 96, 64
+    pics = []
+    for ptype, disp, f, b in S.gop_ibbp(6):
+        t = S.make_picture(rng, cw, ch, ptype, force_dir=2 if (ptype == S.PIC_B and f is None) else None)
+        t["display"] = disp
+        pics.append(t)
+    data, _ = W.write_stream(pics, cw, ch, cw, ch, gop_starts=[0], slice_mbs=slice_mbs)
+    path = str(tmp_path / "s.jsv")
+    with open(path, "wb") as fh:
+        fh.write(data)
+    cli = os.path.join(ROOT, "mpeg1video-decoder-webgl_amd", "js", "cli.js")
+    out = subprocess.run(["node", cli, "tensors", path], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    js = json.loads(out.stdout)["pictures"]
+    for threads in (1, 8):
+        _, mine = all_pictures(data, threads=threads)
+        assert len(mine) == len(js) == len(pics)
+        for i, (p, j, t) in enumerate(zip(mine, js, pics)):
+            assert p["n_slices"] == -(-24 // slice_mbs)
+            assert sha(p["coef_y"]) == j["sha"]["coefY"] == sha(t["coef_y"].astype("<i2")), (threads, i)
+            assert sha(p["coef_cb"]) == j["sha"]["coefCb"] and sha(p["coef_cr"]) == j["sha"]["coefCr"], (threads, i)
+            assert sha(p["qscale"]) == j["sha"]["qscale"] and sha(p["intra"]) == j["sha"]["intra"], (threads, i)
+            if p["type"] != 1:
+                assert sha(p["mv_fwd"]) == j["sha"]["mvFwd"] and sha(p["repadd"]) == j["sha"]["repadd"], (threads, i)
+            if p["type"] == 3:
+                assert sha(p["mv_bwd"]) == j["sha"]["mvBwd"] and sha(p["mb_dir"]) == j["sha"]["mbDir"], (threads, i)

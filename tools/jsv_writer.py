@@ -198,8 +198,9 @@ def _mb_blocks(t, mbx, mby):
     return out
 
 
-def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0)):
-    """One picture, one slice per macroblock row."""
+def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0), slice_mbs=None):
+    """One picture.  slice_mbs None: one slice per macroblock row; else a new slice every slice_mbs
+    macroblocks in raster order (slices then start mid-row and may span rows, as MPEG-1 allows)."""
     ptype = t["type"]
     mbw, mbh = cw // 16, ch // 16
     bw.start_code(START_PICTURE)
@@ -214,9 +215,11 @@ def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0)):
         bw.put(f_code[1], 3)
     bw.put(0, 1)                                           # extra_bit_picture
     types = {PIC_I: MBTYPE_I, PIC_P: MBTYPE_P, PIC_B: MBTYPE_B}[ptype]
-    for mby in range(mbh):
-        bw.start_code(mby + 1)
-        qcur = int(t["qscale"][mby * mbw])
+    per_slice = slice_mbs or mbw
+    for first in range(0, mbw * mbh, per_slice):
+        last = min(first + per_slice, mbw * mbh) - 1
+        bw.start_code(first // mbw + 1)
+        qcur = int(t["qscale"][first])
         if qcur < 1:
             qcur = 1
         bw.put(qcur, 5)
@@ -224,10 +227,10 @@ def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0)):
         dc_pred = [128, 128, 128]
         pmv_f = [0, 0]
         pmv_b = [0, 0]
-        last_coded = -1
+        last_coded = first - (first % mbw) - 1            # the slice's address origin: row start - 1
         prev_intra = False
-        for mbx in range(mbw):
-            mb = mby * mbw + mbx
+        for mb in range(first, last + 1):
+            mbx, mby = mb % mbw, mb // mbw
             intra = bool(t["intra"][mb])
             blocks = _mb_blocks(t, mbx, mby)
             cbp = 0
@@ -241,7 +244,7 @@ def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0)):
             d = int(t["mb_dir"][mb]) & 3 if ptype == PIC_B else 1
             # a P macroblock without coefficients and with a zero vector may be skipped, but never
             # the first or last one of a slice
-            if ptype == PIC_P and not intra and cbp == 0 and mvf == [0, 0] and 0 < mbx < mbw - 1:
+            if ptype == PIC_P and not intra and cbp == 0 and mvf == [0, 0] and first < mb < last:
                 continue
             flags = 0
             if intra:
@@ -261,10 +264,12 @@ def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0)):
                 flags |= 0x10
             if flags not in types:                         # e.g. P: quant without pattern does not exist
                 flags &= ~0x10
-            skipped = mbx - last_coded - 1
-            if skipped and ptype == PIC_P:
+            skipped = mb - last_coded - 1
+            if mb == first:
+                skipped = mbx                              # address increment from the row start, nothing is skipped
+            elif skipped and ptype == PIC_P:
                 pmv_f = [0, 0]                             # skipped P macroblocks reset the predictor
-            if skipped:
+            if skipped and mb != first:
                 dc_pred = [128, 128, 128]
             _put_mba(bw, skipped + 1)
             bw.vlc(types[flags])
@@ -295,12 +300,12 @@ def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0)):
                 if cbp & (1 << (5 - b)):
                     comp = 0 if b < 4 else b - 3
                     dc_pred[comp] = _put_block(bw, blocks[b], intra, b >= 4, dc_pred[comp])
-            last_coded = mbx
+            last_coded = mb
             prev_intra = intra
 
 
 def write_stream(pictures, cw, ch, frame_w=None, frame_h=None, rate_idx=3, gop_starts=None,
-                 qm_intra=None, qm_non_intra=None, key_map=True, f_code=(2, 2)):
+                 qm_intra=None, qm_non_intra=None, key_map=True, f_code=(2, 2), slice_mbs=None):
     """pictures: tensors dicts in CODED order, each with 'display' (temporal reference inside
     its GOP).  gop_starts: indices into `pictures` where a sequence header + GOP header go.
     Returns bytes."""
@@ -340,7 +345,7 @@ def write_stream(pictures, cw, ch, frame_w=None, frame_h=None, rate_idx=3, gop_s
             body.put(int(frame_no - sec * rate) & 63, 6)
             body.put(1, 1)                                 # closed_gop
             body.put(0, 1)                                 # broken_link
-        write_picture(body, t, cw, ch, t.get("display", 0), f_code=f_code)
+        write_picture(body, t, cw, ch, t.get("display", 0), f_code=f_code, slice_mbs=slice_mbs)
         frame_no += 1
     body.start_code(START_END)
     body.buf += bytes(8)                                   # tail so the last start-code scan terminates
