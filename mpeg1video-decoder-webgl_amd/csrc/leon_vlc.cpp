@@ -199,6 +199,19 @@ enum { START_PICTURE = 0x00, START_SLICE_FIRST = 0x01, START_SLICE_LAST = 0xAF, 
 
 struct SliceJob { int code; size_t bitpos; };
 
+// What one slice contributed to one macroblock row: four entry streams (upper and lower luma block
+// row, Cb, Cr), each already ordered by group because a slice walks its macroblocks left to right,
+// plus the entry count per group.  No sort is needed afterwards -- the streams are concatenated.
+struct RowRun {
+    int mb_row = 0;
+    std::vector<uint32_t> ent[4];
+    std::vector<uint32_t> cnt[4];
+};
+struct alignas(128) SliceOut {             // one per slice; written by exactly one worker
+    std::vector<RowRun> runs;
+    size_t used = 0;
+};
+
 }  // namespace
 
 struct leon_vlc_stream {
@@ -229,10 +242,7 @@ struct leon_vlc_stream {
     std::atomic<int> busy{0};
     std::vector<SliceJob> jobs;
     std::atomic<size_t> next_job{0};
-    // per thread: (group << 32) | entry.  Each list header on its own cache lines: push_back
-    // rewrites the end pointer, and neighbouring headers would ping-pong between cores.
-    struct alignas(128) ItemList { std::vector<uint64_t> v; };
-    std::vector<ItemList> items;
+    std::vector<SliceOut> slice_out;           // indexed like jobs; buffers are reused from picture to picture
     std::atomic<int> slice_error{0};
     char slice_err_text[160] = "";
     std::mutex err_mu;
@@ -243,7 +253,8 @@ namespace {
 struct SliceCtx {
     leon_vlc_stream* s;
     Bits r;
-    std::vector<uint64_t>* out;
+    SliceOut* sout;
+    RowRun* run = nullptr;
     int mb_addr = 0, mb_row = 0, mb_col = 0;
     bool slice_begin = true;
     int fw_h = 0, fw_v = 0, fw_h_prev = 0, fw_v_prev = 0, bw_h = 0, bw_v = 0, bw_h_prev = 0, bw_v_prev = 0, prev_dir = 0;
@@ -291,19 +302,21 @@ void decode_motion_vectors(SliceCtx& c)
 // decoders/jsv.js:1338-1525 (decodeBlockGL): raw levels, emitted as sparse entries
 bool decode_block(SliceCtx& c, int block)
 {
-    leon_vlc_stream* s = c.s;
     Bits& r = c.r;
     const Tables& T = tables();
-    uint32_t gid, bq;
+    // stream of the current row run and group inside the row
+    int stream;
+    uint32_t grow, bq;
     if (block < 4) {
-        const int rb = c.mb_row * 2 + (block >> 1), qb = c.mb_col * 2 + (block & 1);
-        gid = (uint32_t)(rb * s->gy + (qb >> 3));
+        const int qb = c.mb_col * 2 + (block & 1);
+        stream = block >> 1;
+        grow = (uint32_t)(qb >> 3);
         bq = (uint32_t)(qb & 7);
     } else {
-        gid = (uint32_t)(s->n_y + (block == 5 ? s->n_c : 0) + c.mb_row * s->gc + (c.mb_col >> 3));
+        stream = block - 2;                                  // 2 = Cb, 3 = Cr
+        grow = (uint32_t)(c.mb_col >> 3);
         bq = (uint32_t)(c.mb_col & 7);
     }
-    const uint64_t ghi = (uint64_t)gid << 32;
     const uint32_t boff = (bq * 16u) << 16;
     int n = 0, c_dc_pending = 0;
     if (c.mb_intra) {
@@ -326,9 +339,9 @@ bool decode_block(SliceCtx& c, int block)
     const uint8_t* const bytes = r.b;
     const size_t end_bits = r.nbytes * 8;
     size_t pos = r.pos;
-    uint64_t tmp[64];
+    uint32_t tmp[64];
     int k = 0;
-    if (c.mb_intra && (int16_t)c_dc_pending != 0) tmp[k++] = ghi | boff | (uint16_t)(int16_t)c_dc_pending;
+    if (c.mb_intra && (int16_t)c_dc_pending != 0) tmp[k++] = boff | (uint16_t)(int16_t)c_dc_pending;
     for (;;) {
         if (pos >= end_bits) { r.pos = pos; r.bad = true; c.err = "bitstream ends inside a block"; return false; }
         uint64_t w;
@@ -367,10 +380,13 @@ bool decode_block(SliceCtx& c, int block)
         n += run;
         if (n > 63) { r.pos = pos; c.err = "coefficient index overflow"; return false; }
         const uint32_t z = kZigZag[n++];
-        if (level != 0) tmp[k++] = ghi | boff | (((z >> 3) * 128u + (z & 7u) * 2u) << 16) | (uint16_t)(int16_t)level;
+        if (level != 0) tmp[k++] = boff | (((z >> 3) * 128u + (z & 7u) * 2u) << 16) | (uint16_t)(int16_t)level;
     }
     r.pos = pos;
-    c.out->insert(c.out->end(), tmp, tmp + k);
+    if (k) {
+        c.run->ent[stream].insert(c.run->ent[stream].end(), tmp, tmp + k);
+        c.run->cnt[stream][grow] += (uint32_t)k;
+    }
     return !r.bad;
 }
 
@@ -413,6 +429,16 @@ int decode_macroblock(SliceCtx& c)
     if (mb < 0 || mb >= s->mbsize) { c.err = "macroblock address outside the picture"; return 0; }
     c.mb_row = mb / s->mbw;
     c.mb_col = mb % s->mbw;
+    if (!c.run || c.run->mb_row != c.mb_row) {
+        SliceOut& so = *c.sout;
+        if (so.used == so.runs.size()) so.runs.emplace_back();
+        c.run = &so.runs[so.used++];
+        c.run->mb_row = c.mb_row;
+        for (int k = 0; k < 4; k++) {
+            c.run->ent[k].clear();
+            c.run->cnt[k].assign((size_t)(k < 2 ? s->gy : s->gc), 0u);
+        }
+    }
     const int mb_type = r.vlc(T.mbtype[type]);
     if (r.bad) { c.err = "invalid macroblock type"; return 0; }
     c.mb_intra = mb_type & 0x01;
@@ -448,14 +474,15 @@ int decode_macroblock(SliceCtx& c)
 }
 
 // decoders/jsv.js:683-706
-void decode_slice(leon_vlc_stream* s, const SliceJob& job, std::vector<uint64_t>* out)
+void decode_slice(leon_vlc_stream* s, const SliceJob& job, SliceOut* out)
 {
     SliceCtx c;
     c.s = s;
     c.r = s->r;
     c.r.pos = job.bitpos;
     c.r.bad = false;
-    c.out = out;
+    c.sout = out;
+    out->used = 0;
     c.mb_addr = (job.code - 1) * s->mbw - 1;
     c.qs = (int)c.r.get(5);
     while (c.r.get(1) && !c.r.bad) c.r.skip(8);
@@ -475,7 +502,8 @@ void run_jobs(leon_vlc_stream* s, int tid)
     for (;;) {
         const size_t j = s->next_job.fetch_add(1);
         if (j >= s->jobs.size()) break;
-        decode_slice(s, s->jobs[j], &s->items[(size_t)tid].v);
+        decode_slice(s, s->jobs[j], &s->slice_out[j]);
+        (void)tid;
     }
 }
 
@@ -606,7 +634,8 @@ int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
     }
     if (code >= 0) r.pos -= 32;                                    // rewind(32)
 
-    for (auto& l : s->items) l.v.clear();
+    if (s->slice_out.size() < s->jobs.size()) s->slice_out.resize(s->jobs.size());
+    for (size_t j = 0; j < s->jobs.size(); j++) s->slice_out[j].used = 0;
     s->next_job.store(0);
     s->slice_error.store(0);
     const int helpers = (int)s->workers.size();
@@ -632,26 +661,40 @@ int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
     }
     if (s->slice_error.load()) return fail(LEON_VLC_ERR_STREAM, "%s", s->slice_err_text);
 
-    // counting sort of the (group, entry) items into per-group runs
+    // assemble: per-group counts from every run, prefix sums, then the run streams are copied group
+    // by group (a group that two slices share -- a slice boundary inside it -- stays contiguous)
     const size_t ng = (size_t)s->info.n_groups;
     s->grp_off.assign(ng + 1, 0);
-    size_t total = 0;
-    for (auto& l : s->items) {
-        total += l.v.size();
-        for (uint64_t it : l.v) {
-            const uint32_t g = (uint32_t)(it >> 32);
-            if (g < ng) s->grp_off[g + 1]++;
+    auto base_of = [&](const RowRun& rr, int k) -> size_t {
+        return k < 2 ? (size_t)(2 * rr.mb_row + k) * (size_t)s->gy
+                     : (size_t)s->n_y + (k == 3 ? (size_t)s->n_c : 0) + (size_t)rr.mb_row * (size_t)s->gc;
+    };
+    for (size_t j = 0; j < s->jobs.size(); j++)
+        for (size_t u = 0; u < s->slice_out[j].used; u++) {
+            const RowRun& rr = s->slice_out[j].runs[u];
+            for (int k = 0; k < 4; k++) {
+                const size_t base = base_of(rr, k);
+                for (size_t g = 0; g < rr.cnt[k].size(); g++) s->grp_off[base + g + 1] += rr.cnt[k][g];
+            }
         }
-    }
     for (size_t g = 0; g < ng; g++) s->grp_off[g + 1] += s->grp_off[g];
     s->entries.resize(s->grp_off[ng]);
     s->cursor.assign(s->grp_off.begin(), s->grp_off.end() - 1);
-    for (auto& l : s->items)
-        for (uint64_t it : l.v) {
-            const uint32_t g = (uint32_t)(it >> 32);
-            if (g < ng) s->entries[s->cursor[g]++] = (uint32_t)it;
+    for (size_t j = 0; j < s->jobs.size(); j++)
+        for (size_t u = 0; u < s->slice_out[j].used; u++) {
+            const RowRun& rr = s->slice_out[j].runs[u];
+            for (int k = 0; k < 4; k++) {
+                const size_t base = base_of(rr, k);
+                const uint32_t* src = rr.ent[k].data();
+                for (size_t g = 0; g < rr.cnt[k].size(); g++) {
+                    const uint32_t n = rr.cnt[k][g];
+                    if (!n) continue;
+                    memcpy(s->entries.data() + s->cursor[base + g], src, (size_t)n * 4);
+                    s->cursor[base + g] += n;
+                    src += n;
+                }
+            }
         }
-    (void)total;
 
     out->type = type;
     out->temporal_reference = s->temporal_reference;
@@ -733,7 +776,6 @@ int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_strea
     if (nt > 64) nt = 64;
     s->n_threads = nt;
     s->info.threads = (uint32_t)nt;
-    s->items.resize((size_t)nt);
     for (int t = 1; t < nt; t++) s->workers.emplace_back(worker_main, s, t);
     *out = s;
     return LEON_VLC_OK;
