@@ -1,10 +1,10 @@
 """CPU: two independent restatements of the GLSL path must agree bit for bit --
-oracle/leon_oracle.c (image-space integers) vs tools/glsl_literal.py (the emulated GL
+oracle/leon_oracle.c (image-space integers) vs oracle/glsl_literal.py (the emulated GL
 machine: textures, normalised coordinates, fragments, float32 where the shader says float)."""
 import numpy as np
 import pytest
 
-import glsl_literal as G
+from oracle import glsl_literal as G
 from oracle import oracle_py as O
 
 
