@@ -77,6 +77,13 @@ def test_config2_i_only_352x240(L, O, S):
     _run_sequence(L, O, 352, 240, pics)
 
 
+def test_config3_1280x720_ippp_gop16(L, O, S):
+    """BASELINE config 3: 1280x720, GOP = I + 15 P, per-macroblock vectors uniform in +-31 half-pel
+    kept inside the picture, 10 % intra-in-P, 15 % skipped, random coded-block patterns."""
+    rng = np.random.default_rng(720)
+    _run_sequence(L, O, 1280, 720, _chain(S, rng, 1280, 720, S.gop_ippp(16)), n_slots=16)
+
+
 def test_ippp_in_picture_vectors(L, O, S):
     rng = np.random.default_rng(1)
     _run_sequence(L, O, 176, 144, _chain(S, rng, 176, 144, S.gop_ippp(6)))
