@@ -604,13 +604,18 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     const uint32_t out_voff = ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)x0) | (valid ? 0u : kOobBit);
     const uint32_t half_step = CHROMA ? 0u : 8u * (uint32_t)W;   // luma: next block row; chroma: next plane
     RefRows rfh[2], rbh[2];
+    // B pictures: a wave whose macroblocks all predict from one side only (the leading pictures of
+    // a closed GOP, runs of forward- or backward-only macroblocks) neither fetches nor interpolates
+    // the other reference.  Wave-uniform, so it costs two scalar tests.
+    const bool any_f = TYPE != 3 || __builtin_amdgcn_ballot_w64(usef) != 0;
+    const bool any_b = TYPE == 3 && __builtin_amdgcn_ballot_w64(useb) != 0;
     if (TYPE != 1) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int Rh = CHROMA ? Rt : 2 * Rt + h;
             const uint32_t po = CHROMA ? (h == 0 ? ysz : ysz + (ysz >> 2)) : 0u;
-            rfh[h] = fetch_rows(gptr(pd.ref_fwd) + po, W, H, 8 * Rh + hi3, pxA, ayA, ohA, ovA, inA, hi3 == 7);
-            if (TYPE == 3) rbh[h] = fetch_rows(gptr(pd.ref_bwd) + po, W, H, 8 * Rh + hi3, pxB, ayB, ohB, ovB, inB, hi3 == 7);
+            if (any_f) rfh[h] = fetch_rows(gptr(pd.ref_fwd) + po, W, H, 8 * Rh + hi3, pxA, ayA, ohA, ovA, inA, hi3 == 7);
+            if (TYPE == 3 && any_b) rbh[h] = fetch_rows(gptr(pd.ref_bwd) + po, W, H, 8 * Rh + hi3, pxB, ayB, ohB, ovB, inB, hi3 == 7);
         }
     }
 #pragma unroll
@@ -727,11 +732,17 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
 
         // ---- stage 4: prediction, add, clamp, store ------------------------------------------
         if (TYPE != 1) {
-            finish_rows(rf, ovA, hi3 == 7, lane);
-            v2u pred = predict8(rf);
+            v2u pred = {0u, 0u};
+            if (any_f) {
+                finish_rows(rf, ovA, hi3 == 7, lane);
+                pred = predict8(rf);
+            }
             if (TYPE == 3) {
-                finish_rows(rb, ovB, hi3 == 7, lane);
-                v2u pb = predict8(rb);
+                v2u pb = {0u, 0u};
+                if (any_b) {
+                    finish_rows(rb, ovB, hi3 == 7, lane);
+                    pb = predict8(rb);
+                }
                 v2u pf = usef ? pred : pb;
                 pb = useb ? pb : pred;
                 pred.x = __builtin_amdgcn_lerp(pf.x, pb.x, 0x01010101u);
