@@ -84,6 +84,13 @@ def test_config3_1280x720_ippp_gop16(L, O, S):
     _run_sequence(L, O, 1280, 720, _chain(S, rng, 1280, 720, S.gop_ippp(16)), n_slots=16)
 
 
+def test_large_picture_4096x2304(L, O, S):
+    """Well past the BASELINE size: 36 864 macroblocks, 1 152 luma groups per block row pair."""
+    rng = np.random.default_rng(4096)
+    gop = [(S.PIC_I, 0, None, None), (S.PIC_P, 2, 0, None), (S.PIC_B, 1, 0, 2)]
+    _run_sequence(L, O, 4096, 2304, _chain(S, rng, 4096, 2304, gop), n_slots=4)
+
+
 def test_ippp_in_picture_vectors(L, O, S):
     rng = np.random.default_rng(1)
     _run_sequence(L, O, 176, 144, _chain(S, rng, 176, 144, S.gop_ippp(6)))
