@@ -119,11 +119,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t buf_rsrc(const void* p)
 {
     return __builtin_amdgcn_make_buffer_rsrc((void*)p, 0, 0x7fffffff, 0x00020000);
 }
-__device__ __forceinline__ v4i buf_load_v4i(const void* base, uint32_t byte_off)
-{
-    v4u r = __builtin_amdgcn_raw_buffer_load_b128(buf_rsrc(base), (int)byte_off, 0, 0);
-    return v4i{(int)r.x, (int)r.y, (int)r.z, (int)r.w};
-}
 // Lanes that must not touch memory carry this bit in their 32-bit buffer offset: it is past
 // num_records of every resource above, so the load returns 0 and the store is dropped by the
 // bounds check -- no exec-mask branch around the instruction, and the number of outstanding
@@ -324,20 +319,13 @@ __device__ __forceinline__ ColOut butterfly8_col(const int (&X)[8], int n_live)
     }
 }
 
-// COL_INT_3 for one NON-ZERO coefficient.  qO = quantiser_scale * matrix entry,
-// pm = premultiplier, nim = -1 for a non-intra block, 0 for an intra block.
-__device__ __forceinline__ int dequant_nz(int X, int qO, int pm, int nim, int lo2048, int hi2047)
-{
-    int x2 = (X << 1) + (sign3(X) & nim);             // X*2, += sign(X) for non-intra
-    int t = mul24_asm(x2, qO);                        // |x2| < 2^17, qO < 2^13
-    int f = t >> 4;                                   // floor(./16)
-    f = (f - med3_asm(f, 0, 1)) | 1;                  // even -> toward zero; 0 -> +1
-    f = med3_asm(f, lo2048, hi2047);
-    return __mul24(f, pm);
-}
-// The same for a coefficient that may be zero, branch-free: sign(X) & 1 replaces the constant 1
-// of the oddification, so X == 0 gives 0*q -> 0 - 0 -> | 0 -> 0 (the shader's `continue`),
-// and every X != 0 takes exactly the path above.
+// COL_INT_3 (decoders/shaders/mpeg1video.js:21-22) for one coefficient, branch-free.  qO =
+// quantiser_scale * matrix entry, pm = premultiplier, nim = -1 for a non-intra block, 0 for an intra
+// block.  X*2 (+ sign(X) for non-intra), * qO, floor(./16), even values step toward zero and 0
+// becomes +1 (the shader's oddification), clamp to [-2048, 2047], * pm.  A zero coefficient must
+// stay zero (the shader's `continue`):
+// sign(X) & 1 replaces the constant 1 of the oddification, so X == 0 gives 0*q -> 0 - 0 -> | 0 -> 0
+// and every X != 0 gets exactly the reference's arithmetic.
 __device__ __forceinline__ int dequant_any(int X, int qO, int pm, int nim, int lo2048, int hi2047)
 {
     const int sg = sign3(X);
