@@ -150,12 +150,6 @@ __device__ __forceinline__ T ldg(const LEON_GLOBAL void* base, uint32_t off)
     return *(const LEON_GLOBAL T*)((const LEON_GLOBAL char*)base + off);
 }
 
-__device__ __forceinline__ int med3_asm(int v, int lo, int hi)
-{
-    int d;
-    asm("v_med3_i32 %0, %1, %2, %3" : "=v"(d) : "v"(v), "v"(lo), "v"(hi));
-    return d;
-}
 // sign(v) in {-1, 0, 1}
 __device__ __forceinline__ int sign3(int v)
 {
@@ -470,8 +464,12 @@ __device__ __forceinline__ v2u predict8(const RefRows& R)
 template <int M>
 __device__ __forceinline__ uint32_t pred_x256(uint32_t pred)
 {
-    // selector bytes: 0x0c = constant 0x00; 0..3 pick bytes of the second operand
-    return __builtin_amdgcn_perm(0u, pred, 0x0c0c000cu | ((uint32_t)M << 8));
+    // selector bytes: 0x0c = constant 0x00; 0..3 pick bytes of the second operand.  The selector
+    // rides in a scalar register (a VOP3 instruction may read one): the builtin makes the compiler
+    // re-materialise it in a vector register in front of every group of uses.
+    uint32_t d;
+    asm("v_perm_b32 %0, 0, %1, %2" : "=v"(d) : "v"(pred), "s"(0x0c0c000cu | ((uint32_t)M << 8)));
+    return d;
 }
 
 // ---- one task = two block groups that share their macroblocks ------------------------
