@@ -88,8 +88,11 @@ int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_strea
 void leon_vlc_close(leon_vlc_stream* s);
 int leon_vlc_get_info(leon_vlc_stream* s, leon_vlc_info* out);
 
-/* = decodeFrame (decoders/jsv.js:426-469) without the reconstruction: parses up to and including
- * the next picture.  The arrays of *out belong to the stream and stay valid until the next call. */
+/* = decodeFrame (decoders/jsv.js:426-469) without the reconstruction: hands out the next picture.
+ * The stream parses one picture AHEAD on its own coordinator thread (two result sets), so the call
+ * usually returns a picture that is already there while the following one is being parsed -- the
+ * caller's submit and the parse overlap.  The arrays of *out belong to the stream and stay valid
+ * until the next call; leon_vlc_get_info reports the sequence state as of the last picture returned. */
 int leon_vlc_next_picture(leon_vlc_stream* s, leon_vlc_picture* out);
 
 /* = jsv.prototype.seek (decoders/jsv.js:1618-1648): position on the key-map entry at or before

@@ -243,6 +243,26 @@ struct leon_vlc_stream {
     std::vector<SliceJob> jobs;
     std::atomic<size_t> next_job{0};
     std::vector<SliceOut> slice_out;           // indexed like jobs; buffers are reused from picture to picture
+
+    // parse-ahead: while the caller works on the picture it was handed, a coordinator thread
+    // already parses the next one into the other of two result sets
+    struct Result {
+        std::vector<uint32_t> grp_off, entries;
+        std::vector<uint8_t> qscale, intra, repadd, mb_dir;
+        std::vector<int16_t> mv_fwd, mv_bwd;
+        leon_vlc_picture pic{};
+        leon_vlc_info info{};
+        int rc = 0;
+        char err[256] = "";
+    };
+    Result results[2];
+    leon_vlc_info info_out{};                  // what leon_vlc_get_info reports: the state at the last returned picture
+    std::thread ahead;
+    std::mutex amu;
+    std::condition_variable acv;
+    int a_request = -1;                        // result set to fill, -1 = none
+    int a_inflight = -1;                       // result set being filled or filled and not yet handed out
+    bool a_done = false, a_quit = false, a_eos = false;
     std::atomic<int> slice_error{0};
     char slice_err_text[160] = "";
     std::mutex err_mu;
@@ -718,6 +738,11 @@ int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
 
 }  // namespace
 
+namespace {
+void ahead_main(leon_vlc_stream* s);
+void ahead_wait(leon_vlc_stream* s);
+}  // namespace
+
 extern "C" {
 
 const char* leon_vlc_last_error(void) { return g_err; }
@@ -777,6 +802,8 @@ int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_strea
     s->n_threads = nt;
     s->info.threads = (uint32_t)nt;
     for (int t = 1; t < nt; t++) s->workers.emplace_back(worker_main, s, t);
+    s->info_out = s->info;
+    s->ahead = std::thread(ahead_main, s);
     *out = s;
     return LEON_VLC_OK;
 }
@@ -784,6 +811,13 @@ int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_strea
 void leon_vlc_close(leon_vlc_stream* s)
 {
     if (!s) return;
+    if (s->a_inflight >= 0) ahead_wait(s);
+    {
+        std::lock_guard<std::mutex> lk(s->amu);
+        s->a_quit = true;
+    }
+    s->acv.notify_all();
+    if (s->ahead.joinable()) s->ahead.join();
     {
         std::lock_guard<std::mutex> lk(s->mu);
         s->quit.store(true);
@@ -796,13 +830,17 @@ void leon_vlc_close(leon_vlc_stream* s)
 int leon_vlc_get_info(leon_vlc_stream* s, leon_vlc_info* out)
 {
     if (!s || !out) return fail(LEON_VLC_ERR_INVALID, "null argument");
-    *out = s->info;
+    *out = s->info_out;
     return LEON_VLC_OK;
 }
 
-int leon_vlc_next_picture(leon_vlc_stream* s, leon_vlc_picture* out)
+}  // extern "C"
+
+namespace {
+
+// = decodeFrame: parse up to and including the next picture into the stream's working arrays
+int next_picture_sync(leon_vlc_stream* s, leon_vlc_picture* out)
 {
-    if (!s || !out) return fail(LEON_VLC_ERR_INVALID, "null argument");
     if (s->ended) return LEON_VLC_END;
     Bits& r = s->r;
     for (;;) {                                                      // decoders/jsv.js:426-469
@@ -822,19 +860,111 @@ int leon_vlc_next_picture(leon_vlc_stream* s, leon_vlc_picture* out)
     }
 }
 
+// parse the next picture and move it into result set k (vector storage is swapped, not copied;
+// the two persistent maps are copied: the next picture keeps updating them)
+void fill_result(leon_vlc_stream* s, int k)
+{
+    leon_vlc_stream::Result& R = s->results[k];
+    leon_vlc_picture p{};
+    g_err[0] = 0;
+    R.rc = next_picture_sync(s, &p);
+    snprintf(R.err, sizeof(R.err), "%s", g_err);
+    R.info = s->info;
+    if (R.rc == LEON_VLC_PICTURE) {
+        R.grp_off.swap(s->grp_off);
+        R.entries.swap(s->entries);
+        R.repadd.swap(s->repadd);
+        R.mv_fwd.swap(s->mv_fwd);
+        R.mv_bwd.swap(s->mv_bwd);
+        R.mb_dir.swap(s->mb_dir);
+        R.qscale = s->qscale;
+        R.intra = s->intra;
+        p.grp_off = R.grp_off.data();
+        p.entries = R.entries.data();
+        p.qscale = R.qscale.data();
+        p.intra = R.intra.data();
+        p.repadd = p.type != 1 ? R.repadd.data() : nullptr;
+        p.mv_fwd = p.type != 1 ? R.mv_fwd.data() : nullptr;
+        p.mv_bwd = p.type == 3 ? R.mv_bwd.data() : nullptr;
+        p.mb_dir = p.type == 3 ? R.mb_dir.data() : nullptr;
+    }
+    R.pic = p;
+}
+
+void ahead_main(leon_vlc_stream* s)
+{
+    for (;;) {
+        int k;
+        {
+            std::unique_lock<std::mutex> lk(s->amu);
+            s->acv.wait(lk, [&] { return s->a_quit || s->a_request >= 0; });
+            if (s->a_quit) return;
+            k = s->a_request;
+            s->a_request = -1;
+        }
+        fill_result(s, k);
+        {
+            std::lock_guard<std::mutex> lk(s->amu);
+            s->a_done = true;
+        }
+        s->acv.notify_all();
+    }
+}
+
+void ahead_start(leon_vlc_stream* s, int k)         // caller holds no lock
+{
+    {
+        std::lock_guard<std::mutex> lk(s->amu);
+        s->a_request = k;
+        s->a_inflight = k;
+        s->a_done = false;
+    }
+    s->acv.notify_all();
+}
+
+void ahead_wait(leon_vlc_stream* s)
+{
+    std::unique_lock<std::mutex> lk(s->amu);
+    s->acv.wait(lk, [&] { return s->a_done; });
+}
+
+}  // namespace
+
+extern "C" {
+
+int leon_vlc_next_picture(leon_vlc_stream* s, leon_vlc_picture* out)
+{
+    if (!s || !out) return fail(LEON_VLC_ERR_INVALID, "null argument");
+    if (s->a_eos) return LEON_VLC_END;
+    if (s->a_inflight < 0) ahead_start(s, 0);
+    ahead_wait(s);
+    const int k = s->a_inflight;
+    leon_vlc_stream::Result& R = s->results[k];
+    s->info_out = R.info;
+    if (R.rc == LEON_VLC_END) {
+        s->a_eos = true;
+        s->a_inflight = -1;
+        return LEON_VLC_END;
+    }
+    ahead_start(s, 1 - k);                          // the other set: `R` stays untouched until the next call
+    if (R.rc < 0) return fail(R.rc, "%s", R.err);
+    *out = R.pic;
+    return LEON_VLC_PICTURE;
+}
+
 int leon_vlc_seek(leon_vlc_stream* s, double seconds, uint64_t* byte_offset)
 {
     if (!s) return fail(LEON_VLC_ERR_INVALID, "null argument");
     uint64_t offset = 0;
-    const uint32_t count = s->info.keymap_count;
+    const uint32_t count = s->info_out.keymap_count;
     if (count) {
-        const double rate = s->info.picture_rate > 0 ? s->info.picture_rate : 25.0;
+        const double rate = s->info_out.picture_rate > 0 ? s->info_out.picture_rate : 25.0;
         auto key_time = [&](uint32_t g) {                           // decoders/jsv.js:315-325
             const uint32_t tc = s->keymap[2 * g + 1];
             const int hour = (tc >> 26) & 31, minute = (tc >> 20) & 63, second = (tc >> 13) & 63, frame = (tc >> 7) & 63;
             return (hour * 60 + minute) * 60 + second + (frame + 1) / rate;
         };
-        const double dur = s->info.duration > 0 ? s->info.duration : 1.0;
+        const double dur = s->info_out.duration > 0 ? s->info_out.duration : 1.0;
         double gf = (double)count * seconds / dur;
         if (gf < 0) gf = 0;
         uint32_t g = (uint32_t)gf;
@@ -844,6 +974,9 @@ int leon_vlc_seek(leon_vlc_stream* s, double seconds, uint64_t* byte_offset)
         offset = s->keymap[2 * g];
     }
     if (offset > s->r.nbytes) return fail(LEON_VLC_ERR_STREAM, "key map entry beyond the stream");
+    if (s->a_inflight >= 0) ahead_wait(s);          // whatever was parsed ahead is dropped
+    s->a_inflight = -1;
+    s->a_eos = false;
     s->r.pos = (size_t)offset * 8;
     s->ended = false;
     s->skip_till_gop = true;
