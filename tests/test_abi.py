@@ -46,10 +46,12 @@ def test_no_cpu_fallback_without_device():
 
 
 def test_product_never_imports_the_oracle():
-    """The oracle is test infrastructure: nothing under the package may reference it."""
-    pkg = os.path.join(ROOT, "mpeg1video-decoder-webgl_amd")
-    for dp, _, fs in os.walk(pkg):
-        for f in fs:
-            if f.endswith((".py", ".cpp", ".h", ".js", ".cc")):
-                src = open(os.path.join(dp, f), errors="replace").read()
-                assert "oracle_py" not in src and "leon_oracle" not in src and "libleon_oracle" not in src, os.path.join(dp, f)
+    """The oracle is test infrastructure: nothing under the package or under tools/ may reference it
+    (only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg do)."""
+    for top in ("mpeg1video-decoder-webgl_amd", "tools", "include"):
+        for dp, _, fs in os.walk(os.path.join(ROOT, top)):
+            for f in fs:
+                if f.endswith((".py", ".cpp", ".h", ".js", ".cc", ".sh")):
+                    src = open(os.path.join(dp, f), errors="replace").read()
+                    assert "oracle_py" not in src and "leon_oracle" not in src and "libleon_oracle" not in src \
+                        and "from oracle" not in src and "import oracle" not in src, os.path.join(dp, f)
