@@ -64,9 +64,10 @@ def test_native_parser_option_gives_the_same_playback():
     assert a == b
 
 
-def test_seek_restarts_at_the_key_entry():
+@pytest.mark.parametrize("native", [False, True])
+def test_seek_restarts_at_the_key_entry(native):
     extra = "p.currentTime = 0.6; p.play(); first.afterSeek = p.framesDisplayed;"
-    r = _run("leon_synth_352x240.jsv", gpu=False, extra=extra)
+    r = _run("leon_synth_352x240.jsv", gpu=False, extra=extra, native=native)
     assert r["first"]["n"] == 24 and r["first"]["afterSeek"] == 24 + 12
     assert "seeking" in r["ev"] and "seeked" in r["ev"] and r["ev"].count("ended") == 2
 
