@@ -68,7 +68,7 @@ def test_stream_decodes_bit_exact_through_node(name, cw, ch, fw, fh, seed, gopsp
         assert p["rgba"] == _sha(O.ycbcr_to_rgba(y, cb, cr, cw, fw, fh, "cpu")), "RGBA of picture %d" % i
 
 
-@pytest.mark.parametrize("name", ["leon_synth_352x240", "ibbp_96x64", "tiny_ip_32x32"])
+@pytest.mark.parametrize("name", ["leon_synth_352x240", "ibbp_96x64", "tiny_ip_32x32", "slices5_ip_96x64"])
 def test_native_front_end_and_sparse_boundary_give_the_same_frames(name):
     """stream -> libleon_vlc (worker threads) -> submitSparse -> planes / RGBA, under Node,
     against the JavaScript-parser + dense-boundary path checked above."""

@@ -38,7 +38,7 @@ def _ref_uploads(pic):
     return d
 
 
-@pytest.mark.parametrize("name", ["tiny_ip_32x32", "leon_synth_352x240", "ibbp_96x64"])
+@pytest.mark.parametrize("name", ["tiny_ip_32x32", "leon_synth_352x240", "ibbp_96x64", "slices5_ip_96x64"])
 def test_tensors_equal_reference_parser(name):
     got = run_cli("tensors", os.path.join(STREAMS, name + ".jsv"))
     ref = load_golden("parser_%s.json" % name)
@@ -114,7 +114,7 @@ def test_key_map_seek():
     assert r == {"n": 12, "first": 1, "off": 58896, "count": 2}
 
 
-@pytest.mark.parametrize("name", ["tiny_ip_32x32", "leon_synth_352x240", "ibbp_96x64"])
+@pytest.mark.parametrize("name", ["tiny_ip_32x32", "leon_synth_352x240", "ibbp_96x64", "slices5_ip_96x64"])
 def test_native_front_end_under_node_equals_the_javascript_parser(name):
     """js/native_decoder.js (libleon_vlc through napi/leon_vlc_napi.node, sparse lists densified)
     against js/jsv_decoder.js: same tensors, same time stamps, same events, picture by picture."""

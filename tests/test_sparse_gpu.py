@@ -129,7 +129,7 @@ def test_malformed_lists_are_rejected_or_harmless(L):
         dec.close()
 
 
-@pytest.mark.parametrize("name", ["tiny_ip_32x32", "leon_synth_352x240", "ibbp_96x64"])
+@pytest.mark.parametrize("name", ["tiny_ip_32x32", "leon_synth_352x240", "ibbp_96x64", "slices5_ip_96x64"])
 def test_stream_to_planes_through_the_native_front_end(L, O, name):
     """bytes -> leon_vlc_next_picture -> leon_submit_sparse, with the anchor bookkeeping of
     jsv.prototype.IDCT_GL (prev_pic_framebuffer, decoders/jsv.js:665) -- against the oracle fed

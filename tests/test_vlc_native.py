@@ -19,7 +19,7 @@ from helpers import ROOT, load_golden
 import leon_vlc_ctypes as V
 
 STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
-NAMES = ["tiny_ip_32x32", "leon_synth_352x240", "ibbp_96x64"]
+NAMES = ["tiny_ip_32x32", "leon_synth_352x240", "ibbp_96x64", "slices5_ip_96x64"]
 sha = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
 
 

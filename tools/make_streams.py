@@ -11,7 +11,7 @@ import synth as S           # noqa: E402
 import jsv_writer as W      # noqa: E402
 
 
-def build(name, cw, ch, fw, fh, gops, seed, **kw):
+def build(name, cw, ch, fw, fh, gops, seed, slice_mbs=None, **kw):
     rng = np.random.default_rng(seed)
     pics, starts = [], []
     for gop in gops:
@@ -21,7 +21,7 @@ def build(name, cw, ch, fw, fh, gops, seed, **kw):
             t = S.make_picture(rng, cw, ch, ptype, force_dir=force, **kw)
             t["display"] = disp
             pics.append(t)
-    data, offs = W.write_stream(pics, cw, ch, fw, fh, gop_starts=starts)
+    data, offs = W.write_stream(pics, cw, ch, fw, fh, gop_starts=starts, slice_mbs=slice_mbs)
     out = os.path.join(ROOT, "tests", "golden", "streams")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, name + ".jsv"), "wb") as f:
@@ -36,3 +36,6 @@ if __name__ == "__main__":
     build("leon_synth_352x240", 352, 240, 352, 240, [S.gop_ippp(12), S.gop_ippp(12)], 0x4C454F4E)
     # B pictures (beyond the reference parser, which drops them): product parser only
     build("ibbp_96x64", 96, 64, 90, 60, [S.gop_ibbp(12), S.gop_ibbp(6)], 7)
+    # slices of 5 macroblocks (6 per row): mid-row starts and row-spanning slices, I + P only so that the
+    # reference parser reads every picture
+    build("slices5_ip_96x64", 96, 64, 96, 64, [S.gop_ippp(6)], 55, slice_mbs=5)
