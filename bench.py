@@ -259,6 +259,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # clocks: ~30 ms of streaming copies before the W warm-up steps, so that a short run (small W) is
+    # not timed on an idle-clocked device; not part of the step, not timed
+    dec.measure_copy_bandwidth(1 << 30, 40)
     for _ in range(args.warmup):
         step()
     fence()
