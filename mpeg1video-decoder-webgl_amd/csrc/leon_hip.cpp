@@ -836,6 +836,16 @@ int leon_timing_enable(leon_decoder* d, int32_t on)
 {
     if (!d) return fail(LEON_ERR_INVALID, "null decoder");
     d->timing = on != 0;
+    if (d->timing && d->ev_pool.size() < 4096) {
+        // events for ~2000 launches up front: creating them one by one would sit inside the caller's
+        // timed region
+        HIP_TRY(hipSetDevice(d->dev));
+        while (d->ev_pool.size() < 4096) {
+            hipEvent_t e = nullptr;
+            HIP_TRY(hipEventCreate(&e));
+            d->ev_pool.push_back(e);
+        }
+    }
     return LEON_OK;
 }
 
