@@ -88,12 +88,14 @@ def pmc_traffic(gops):
         return None, None
     k = json.load(open(path))["kernels"]
     per_type = {}
-    for t, pics_per_gop in ((1, 1), (2, 1), (3, 2)):
+    wg_threads = ((CW // 64 + 0) * (CH // 16) + ((CW // 16 + 7) // 8) * (CH // 16) + 3) // 4 * 256   # threads per picture
+    for t in (1, 2, 3):
         e = k.get("void leon::k_recon<%d, false>" % t)
         if not e or "hbm_read_bytes_corrected" not in e:
             return None, None
-        # the profiled launches held 48 GOPs: 48 I, 48 P, 96 B pictures
-        per_type[t] = (e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]) / (48.0 * pics_per_gop)
+        # pictures in the profiled launches, from their grid size (one workgroup = 4 tasks of one picture)
+        n_pics = e["FETCH_SIZE"]["grid_size"] / float(wg_threads)
+        per_type[t] = (e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]) / n_pics
     # one step = 1 I launch, 3 P launches, 4 B launches (2 B pictures per GOP each)
     step_bytes = gops * (per_type[1] + 3 * per_type[2] + 8 * per_type[3])
     return step_bytes / 8.0, "profiles/r01h_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 FETCH x2 correction)"
@@ -182,7 +184,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=30)
     ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--gops", type=int, default=48, help="independent GOPs per GPU per step")
+    ap.add_argument("--gops", type=int, default=128,
+                    help="independent GOPs per GPU per step (every launch holds that many pictures of a type per "
+                         "GOP position; 128 GOPs = 32 GB of tensors, slots and RGBA output on a 288 GB part)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--boundary", choices=("dense", "sparse"), default="dense",
                     help="dense: the int16 planes the reference uploads (the BASELINE metric); sparse: the same "
