@@ -148,6 +148,36 @@ def cpu_baseline_all_cores(host, gop, budget_s=8.0):
             "fps": done / dt}
 
 
+def cpu_baseline_js(host, gop, budget_s=6.0):
+    """SURVEY.md 8d's CPU baseline in the reference's own language: the plain-JavaScript oracle
+    (oracle/leon_oracle.js, bit-identical to the C oracle) on the same GOP, timed by process.hrtime in
+    Node on one thread and on worker_threads = hardware threads.  None when node is not installed."""
+    import shutil
+    import subprocess
+    import tempfile
+    if shutil.which("node") is None:
+        return None
+    from oracle import oracle_py as O
+    d = tempfile.mkdtemp(prefix="leon_js_gop_")
+    try:
+        O.dump_gop(d, CW, CH, FW, FH, gop, host)
+        n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+        n = max(1, min(n, 64))
+        out = subprocess.run(["node", os.path.join(ROOT, "oracle", "js_baseline.js"), "time", d, str(budget_s), str(n)],
+                             capture_output=True, text=True, timeout=600)
+        if out.returncode != 0:
+            return {"error": out.stderr[-300:]}
+        r = json.loads(out.stdout)
+        return {"kind": "port", "language": "JavaScript (%s)" % r["node"], "unit": "macroblocks/s",
+                "value": r["one_thread"]["macroblocks_per_s"], "cores": 1,
+                "sample": "%d 1080p pictures of the same IBBP GOP (decode + RGBA), oracle/leon_oracle.js, %.1f s"
+                          % (r["one_thread"]["pictures"], r["one_thread"]["seconds"]),
+                "workers": {"value": r["workers"]["macroblocks_per_s"], "cores": r["workers"]["threads"],
+                            "sample": "%d pictures in %.1f s" % (r["workers"]["pictures"], r["workers"]["seconds"])}}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
+
 def cpu_baseline(S, host, gop, budget_s=12.0):
     """The oracle (a scalar C port of the reference's path) on ONE host core, on a bounded
     sample of the same workload: whole 1080p GOPs, decode + RGBA, until ~budget_s."""
@@ -344,6 +374,7 @@ def main():
             cb, outs = cpu_baseline(S, host, gop)
             out["cpu_baseline"] = cb
             out["cpu_baseline_all_cores"] = cpu_baseline_all_cores(host, gop)
+            out["cpu_baseline_js"] = cpu_baseline_js(host, gop)
             # the bench doubles as a parity check of the timed workload: GOP 0 against the oracle
             bad = 0
             for disp in outs:

@@ -123,3 +123,29 @@ def ycbcr_to_rgba(y, cb, cr, coded_w, frame_w, frame_h, mode="cpu"):
     fn(y.ctypes.data_as(C.c_void_p), cb.ctypes.data_as(C.c_void_p), cr.ctypes.data_as(C.c_void_p),
        coded_w, frame_w, frame_h, out.ctypes.data_as(C.c_void_p))
     return out.reshape(frame_h, frame_w, 4)
+
+
+def dump_gop(dirname, cw, ch, fw, fh, gop, pictures, qm=None):
+    """Write one GOP's boundary tensors for oracle/js_baseline.js: manifest.json + raw arrays.
+    gop: [(type, display, fwd, bwd)] in coded order; pictures: {display: tensors dict}."""
+    import json
+    import os
+    os.makedirs(dirname, exist_ok=True)
+    man = {"cw": cw, "ch": ch, "fw": fw, "fh": fh, "gop": [],
+           "qm": [int(v) for v in (default_qm() if qm is None else qm)]}
+    dts = {"coef_y": "<i2", "coef_cb": "<i2", "coef_cr": "<i2", "qscale": "u1", "intra": "u1", "repadd": "u1",
+           "mb_dir": "u1", "mv_fwd": "<i2", "mv_bwd": "<i2"}
+    for ptype, disp, f, b in gop:
+        t = pictures[disp]
+        files = {}
+        for k, dt in dts.items():
+            if t.get(k) is not None:
+                name = "p%d_%s.bin" % (disp, k)
+                np.ascontiguousarray(t[k]).astype(dt).tofile(os.path.join(dirname, name))
+                files[k] = name
+            else:
+                files[k] = None
+        man["gop"].append({"type": int(ptype), "disp": int(disp), "fwd": None if f is None else int(f),
+                           "bwd": None if b is None else int(b), "files": files})
+    with open(os.path.join(dirname, "manifest.json"), "w") as fh_:
+        json.dump(man, fh_)
