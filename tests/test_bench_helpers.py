@@ -1,0 +1,33 @@
+"""CPU: the parts of bench.py that do not need a GPU -- the committed PMC summary it quotes as
+`roofline.traffic`, and the stream index / shard arithmetic of the multi-GPU path."""
+import json
+import os
+
+from helpers import ROOT
+
+import bench
+
+
+def test_pmc_traffic_comes_from_the_committed_profile():
+    traffic, src = bench.pmc_traffic(128)
+    assert traffic is not None and "profiles/" in src
+    path = os.path.join(ROOT, src.split(" ")[0])
+    assert os.path.exists(path), path
+    k = json.load(open(path))["kernels"]
+    assert all("void leon::k_recon<%d, false>" % t in k for t in (1, 2, 3))
+    # HBM bytes per launch must be close to the algorithmic bytes of the same launches:
+    # per GOP and step 1 I, 3 P, 6 bidirectional and 2 backward-only B pictures
+    mbs = (bench.CW // 16) * (bench.CH // 16)
+    algo = 128 * mbs * (1154 + 3 * 1542 + 6 * 1930 + 2 * 1542) / 8.0
+    assert 0.97 < traffic / algo < 1.06, (traffic, algo)
+
+
+def test_kernel_stats_of_the_same_round_are_committed():
+    tag = bench.pmc_traffic(1)[1].split("/")[1].split("_")[0]          # e.g. r01i
+    for suffix in ("_kernel_stats.csv", "_pmc.json", "_bench_line_under_rocprofv3.json"):
+        assert os.path.exists(os.path.join(ROOT, "profiles", tag + suffix)), tag + suffix
+    line = json.load(open(os.path.join(ROOT, "profiles", tag + "_bench_line_under_rocprofv3.json")))
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline"):
+        assert key in line, key
+    assert {"bound", "achieved", "peak", "unit", "frac", "traffic"} <= set(line["roofline"])
