@@ -94,3 +94,30 @@ def test_ring_exhaustion_throws_like_the_reference():
     """ % (js, addon, os.path.join(STREAMS, "leon_synth_352x240.jsv"))], capture_output=True, text=True, timeout=120)
     assert out.returncode == 0, out.stderr
     assert out.stdout.startswith("13 frames then:") and "no free render buffers" in out.stdout
+
+
+def test_addon_rejects_malformed_sparse_pictures():
+    """submitSparse: too-short arrays raise a TypeError in the addon; lists the library rejects
+    (offsets not closed by nEntries) surface as an Error carrying leon_last_error()."""
+    import subprocess
+    addon = os.path.join(ROOT, "mpeg1video-decoder-webgl_amd", "napi", "leon_napi.node")
+    out = subprocess.run(["node", "-e", """
+      const leon = require(%r);
+      const h = leon.create({codedWidth: 64, codedHeight: 48, nSlots: 4});
+      const nGroups = 2 * 3 * 1 + 2 * 3 * 1, mbs = 12, res = [];
+      const pic = (over) => Object.assign({type: 1, outSlot: 0, nEntries: 0, grpOff: new Uint32Array(nGroups + 1),
+        entries: new Uint32Array(0), qscale: new Uint8Array(mbs).fill(8), intra: new Uint8Array(mbs).fill(255)}, over);
+      h.submitSparse(pic({}));                                             // an empty picture is fine
+      try { h.submitSparse(pic({grpOff: new Uint32Array(3)})); res.push('accepted'); } catch (e) { res.push(e.constructor.name); }
+      const bad = new Uint32Array(nGroups + 1); bad[2] = 7;
+      try { h.submitSparse(pic({grpOff: bad})); res.push('accepted'); } catch (e) { res.push(e.constructor.name + ': ' + e.message); }
+      try { h.submitSparse(pic({type: 2, outSlot: 1, refFwdSlot: 0})); res.push('accepted'); } catch (e) { res.push(e.message); }
+      h.sync(); h.destroy();
+      console.log(JSON.stringify(res));
+    """ % addon], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stderr
+    import json
+    r = json.loads(out.stdout)
+    assert r[0] == "TypeError"
+    assert r[1].startswith("Error: leon error -1") and "grp_off" in r[1]
+    assert "repadd" in r[2]                       # a P picture without its maps
