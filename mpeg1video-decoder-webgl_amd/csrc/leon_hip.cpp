@@ -718,6 +718,10 @@ int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, vo
     G.flavour = flavour;
     G.slot_stride_lo = (uint32_t)(d->slot_stride & 0xffffffffu);
     G.slot_stride_hi = (uint32_t)(d->slot_stride >> 32);
+    {
+        const uint32_t c4 = (uint32_t)G.fw >> 2;
+        G.inv_cols4 = c4 <= 1 ? 0u : (uint32_t)(((1ull << 32) + c4 - 1) / c4);
+    }
     TimedLaunch tl{};
     if (d->timing) {
         tl.a = get_event(d);
@@ -733,7 +737,7 @@ int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, vo
             hipLaunchKernelGGL(k_fill255, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, cs, (uint32_t*)rgba_device, nd);
         }
         if (G.cols > 0 && G.rows > 0 && (G.fw & 3) == 0 && ((size_t)rgba_device & 15) == 0)
-            hipLaunchKernelGGL(k_rgba_twin4, dim3((G.fw / 4 + 255) / 256, G.rows, n), dim3(256), 0, cs,
+            hipLaunchKernelGGL(k_rgba_twin4, dim3(((unsigned)(G.fw / 4) * (unsigned)G.rows + 255) / 256, 1, n), dim3(256), 0, cs,
                                d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
         else if (G.cols > 0 && G.rows > 0)
             hipLaunchKernelGGL(k_rgba_twin, dim3((G.cols + 255) / 256, G.rows, n), dim3(256), 0, cs,

@@ -806,6 +806,7 @@ struct RgbaGeom {
     int32_t n;                   // frames in the batch
     int32_t flavour;             // 0 CPU twin (fp64), 1 GL (fp32)
     uint32_t slot_stride_lo, slot_stride_hi;   // bytes between slots
+    uint32_t inv_cols4;          // ceil(2^32 / (fw/4)): the 4x2 kernel walks a frame linearly
 };
 
 // Uint8ClampedArray store: clamp, round half to even (2^52+2^51 trick; |x| < 2^31)
@@ -862,10 +863,14 @@ __global__ __launch_bounds__(256) void k_rgba_twin(const uint8_t* __restrict__ s
 __global__ __launch_bounds__(256) void k_rgba_twin4(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
                                                     uint8_t* __restrict__ rgba, RgbaGeom G)
 {
-    const int col4 = blockIdx.x * blockDim.x + threadIdx.x;     // group of 4 columns
-    const int row = blockIdx.y;                                 // row pair
+    // one thread per (row pair, group of 4 columns), numbered linearly through the frame: a 1920-wide
+    // row pair is 7.5 waves, and a row-shaped grid would leave every eighth wave half empty
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t cols4 = (uint32_t)G.fw >> 2;
+    if (idx >= cols4 * (uint32_t)G.rows) return;
+    const int row = (int)(G.inv_cols4 ? __umulhi(idx, G.inv_cols4) : idx);   // exact: idx * cols4 < 2^32
+    const int col4 = (int)(idx - (uint32_t)row * cols4);
     const int f = blockIdx.z;
-    if (col4 * 4 >= G.fw) return;
     const size_t stride = ((size_t)G.slot_stride_hi << 32) | G.slot_stride_lo;
     const uint8_t* Y = slots + (size_t)slot_ids[f] * stride;
     const uint8_t* Cb = Y + (size_t)G.cw * G.ch;
