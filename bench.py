@@ -79,11 +79,11 @@ def build_workload(L, S, dec, torch, gops, seed, sparse=False):
 
 def pmc_traffic(gops):
     """HBM bytes per k_recon launch from the committed rocprofv3 PMC passes of this same workload
-    (profiles/r01i_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
+    (profiles/r01j_pmc.json: separate --pmc FETCH_SIZE / WRITE_SIZE runs; FETCH_SIZE doubled as
     MI355X_MICROARCH.md prescribes for wide coalesced reads on gfx950, WRITE_SIZE exact).
     Counters cannot be read from inside this process, so this is the profiled figure of the
     identical launches, scaled by the GOP count; None when the file is absent."""
-    path = os.path.join(ROOT, "profiles", "r01i_pmc.json")
+    path = os.path.join(ROOT, "profiles", "r01j_pmc.json")
     if not os.path.exists(path):
         return None, None
     k = json.load(open(path))["kernels"]
@@ -98,7 +98,7 @@ def pmc_traffic(gops):
         per_type[t] = (e["hbm_read_bytes_corrected"] + e["hbm_write_bytes"]) / n_pics
     # one step = 1 I launch, 3 P launches, 4 B launches (2 B pictures per GOP each)
     step_bytes = gops * (per_type[1] + 3 * per_type[2] + 8 * per_type[3])
-    return step_bytes / 8.0, "profiles/r01i_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 FETCH x2 correction)"
+    return step_bytes / 8.0, "profiles/r01j_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, gfx950 FETCH x2 correction)"
 
 
 def _cpu_gops(O, host, gop, budget_s, counter, slot):
