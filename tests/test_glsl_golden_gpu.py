@@ -1,0 +1,84 @@
+"""GPU: libleon_hip.so (through the C ABI) against the vectors produced by executing the
+reference's own shader text on tools/softgl (tests/golden/glsl_*.json, see
+tests/test_glsl_golden.py).  Bit-exact, dense and sparse boundary."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ROOT, hip_submit, hip_submit_sparse, planes_flat
+from test_glsl_golden import CASES, STREAMS, case_tensors, sha, unz
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import leon_ctypes
+    leon_ctypes.load()
+    return leon_ctypes
+
+
+def split(flat, cw, ch):
+    n = cw * ch
+    return flat[:n].reshape(ch, cw), flat[n:n + n // 4].reshape(ch // 2, cw // 2), flat[n + n // 4:].reshape(ch // 2, cw // 2)
+
+
+@pytest.mark.parametrize("sparse", [False, True], ids=["dense", "sparse"])
+@pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
+def test_hip_equals_reference_shaders(L, case, sparse):
+    cw, ch = case["coded_w"], case["coded_h"]
+    qm = unz(case["quant_matrices"])
+    dec = L.Decoder(cw, ch, n_slots=4)
+    try:
+        dec.set_quant_matrices(qm[:64], qm[64:])
+        keep = []
+        prev = None
+        for i, p in enumerate(case["pictures"]):
+            t = case_tensors(p)
+            t["slot"] = 1
+            t["ref_fwd"] = None
+            if p["type"] == 2:
+                # predict from the REFERENCE's previous output, so one differing picture cannot hide the next
+                dec.write_planes(0, *split(prev, cw, ch))
+                t["ref_fwd"] = 0
+            (hip_submit_sparse(L, dec, t, keep, cw, ch) if sparse else hip_submit(L, dec, t, keep))
+            got = planes_flat(*dec.read_planes(1))
+            ref = np.concatenate([unz(x) for x in p["planes"]])
+            bad = np.nonzero(got != ref)[0]
+            assert bad.size == 0, "%s picture %d (type %d): %d samples differ, first at %d (got %d want %d)" % (
+                case["name"], i, p["type"], bad.size, bad[0], got[bad[0]], ref[bad[0]])
+            prev = ref
+    finally:
+        dec.close()
+
+
+@pytest.mark.parametrize("s", STREAMS, ids=lambda s: s["stream"])
+def test_stream_through_native_front_end_and_hip(L, s):
+    """stream bytes -> libleon_vlc.so -> leon_submit_sparse -> planes == the reference's own
+    decode of the same bytes (its parser, its IDCT_GL, its shaders on softgl)."""
+    import leon_vlc_ctypes as V
+    data = open(os.path.join(ROOT, "tests", "golden", "streams", s["stream"]), "rb").read()
+    st = V.Stream(data)
+    cw, ch = s["coded_w"], s["coded_h"]
+    qm = unz(s["custom_intra_matrix"])
+    dec = L.Decoder(cw, ch, n_slots=4)
+    try:
+        dec.set_quant_matrices(qm[:64], qm[64:])
+        keep = []
+        n = 0
+        while True:
+            p = st.next_picture(dense=True)
+            if p is None:
+                break
+            r = s["pictures"][n]
+            t = dict(p)
+            t["slot"] = n & 1
+            t["ref_fwd"] = None if p["type"] == 1 else (n & 1) ^ 1
+            hip_submit_sparse(L, dec, t, keep, cw, ch)
+            got = [sha(x) for x in dec.read_planes(n & 1)]
+            assert got == r["planes_sha256"], "picture %d of %s" % (n, s["stream"])
+            n += 1
+        assert n == len(s["pictures"])
+    finally:
+        dec.close()

@@ -21,7 +21,7 @@ def build(name, cw, ch, fw, fh, gops, seed, slice_mbs=None, **kw):
             t = S.make_picture(rng, cw, ch, ptype, force_dir=force, **kw)
             t["display"] = disp
             pics.append(t)
-    data, offs = W.write_stream(pics, cw, ch, fw, fh, gop_starts=starts, slice_mbs=slice_mbs)
+    data, offs = W.write_stream(pics, cw, ch, fw, fh, gop_starts=starts, slice_mbs=slice_mbs, qm_intra=kw.get("qm_intra"))
     out = os.path.join(ROOT, "tests", "golden", "streams")
     os.makedirs(out, exist_ok=True)
     with open(os.path.join(out, name + ".jsv"), "wb") as f:
@@ -39,3 +39,7 @@ if __name__ == "__main__":
     # slices of 5 macroblocks (6 per row): mid-row starts and row-spanning slices, I + P only so that the
     # reference parser reads every picture
     build("slices5_ip_96x64", 96, 64, 96, 64, [S.gop_ippp(6)], 55, slice_mbs=5)
+    # custom intra quantiser matrix in the sequence header (decoders/jsv.js:540-547; a custom NON-intra
+    # matrix never reaches the reference's GPU path, :556, so it is left at the default)
+    from make_glsl_cases import CUSTOM_INTRA
+    build("custom_intra_ip_48x32", 48, 32, 48, 32, [S.gop_ippp(4)], 99, qm_intra=CUSTOM_INTRA.reshape(8, 8))
