@@ -109,8 +109,11 @@ typedef struct leon_sparse_picture {
 typedef struct leon_kernel_stats {
     uint64_t launches;        /* timed launches since leon_timing_reset */
     double   total_ms;        /* sum of their HIP-event durations */
-    double   algorithmic_bytes; /* sum over launches of SURVEY.md 8d bytes (sparse launches: 4 B per entry and
-                                   per group offset in place of the 768 B/MB of dense coefficients) */
+    double   algorithmic_bytes; /* sum over launches of SURVEY.md 8d bytes, priced per macroblock from the picture's
+                                   own maps: I 1154; P 1158 + 384 if predicted (= 8d's 1542); B 1162 + 384 per
+                                   direction used (1546 one-sided, 1930 bidirectional = 8d's figure).  Sparse
+                                   launches: 4 B per entry and per group offset in place of the 768 B/MB of
+                                   dense coefficients */
     uint64_t macroblocks;     /* sum over launches */
 } leon_kernel_stats;
 
@@ -141,10 +144,12 @@ int leon_free_decoded_slots(leon_decoder* d);
  *   decoder's stream.  The arrays may be reused as soon as the call returns. */
 int leon_submit_picture(leon_decoder* d, const leon_picture* pic);
 
-/* Batched IDCT_GL: n mutually independent pictures in ONE kernel launch.
- * mem = LEON_MEM_DEVICE: every pointer in pics[] is a device pointer (resident
- * boundary tensors; the arrays must stay valid until the work completed).
- * mem = LEON_MEM_HOST: staged like leon_submit_picture. */
+/* Batched IDCT_GL: n mutually independent pictures (no picture of the batch writes a slot that
+ * another one writes or reads; checked, LEON_ERR_INVALID otherwise).
+ * mem = LEON_MEM_DEVICE: every pointer in pics[] is a device pointer (resident boundary tensors;
+ * the arrays must stay valid until the work completed); one kernel launch per picture type present.
+ * mem = LEON_MEM_HOST: each picture is staged and launched like leon_submit_picture (n launches);
+ * the batched host path is leon_pipeline_* below. */
 int leon_submit_batch(leon_decoder* d, const leon_picture* pics, int32_t n, int32_t mem);
 
 /* A prepared batch keeps its descriptors on the device so that re-running it costs

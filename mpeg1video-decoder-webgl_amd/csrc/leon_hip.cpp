@@ -58,8 +58,12 @@ struct TimedLaunch {
     uint64_t mbs;
 };
 
-// SURVEY.md 8d / BASELINE.md section 2: algorithmic bytes per macroblock
-double algo_bytes_per_mb(int type) { return type == LEON_PIC_I ? 1154.0 : type == LEON_PIC_P ? 1542.0 : 1930.0; }
+// SURVEY.md 8d / BASELINE.md section 2: algorithmic bytes per macroblock -- priced by what the
+// macroblock itself must move: 768 B of coefficients + 384 B written + its map bytes and vectors,
+// and 384 B per reference it really predicts from.  I 1154; P 1158 + 384 when predicted (= the
+// survey's 1542; an intra macroblock of a P picture reads no reference); B 1162 + 384 per direction
+// used (1546 one-sided, 1930 bidirectional = the survey's figure).
+const double kBytesI = 1154.0, kBytesPBase = 1158.0, kBytesBBase = 1162.0, kBytesRef = 384.0;
 const double kRgbaBytesPerMb = 1408.0;
 
 // dense or sparse picture as the internals see it
@@ -103,6 +107,7 @@ struct leon_batch {
     std::vector<int32_t> out_slots;
     bool sparse = false;
     uint64_t entries_of_type[3] = {0, 0, 0};   // sparse: list lengths per type (algorithmic bytes)
+    double bytes_of_type[3] = {0, 0, 0};       // dense-boundary algorithmic bytes per type, from the pictures' own maps
 };
 
 struct leon_decoder {
@@ -121,6 +126,10 @@ struct leon_decoder {
     size_t slot_stride = 0;      // padded
     uint8_t* d_slots = nullptr;
     std::vector<uint8_t> inuse;
+    // batch independence check (check_batch): which picture of the current batch writes a slot
+    std::vector<uint32_t> writer_epoch;
+    std::vector<int32_t> writer_of;
+    uint32_t epoch = 0;
     Tables h_tables{};
     Tables* d_tables = nullptr;
     uint8_t qm[128];
@@ -148,6 +157,7 @@ struct leon_decoder {
 
 namespace {
 
+// nullptr (and the thread's error text) when the runtime cannot give out another event
 hipEvent_t get_event(leon_decoder* d)
 {
     if (!d->ev_pool.empty()) {
@@ -156,8 +166,26 @@ hipEvent_t get_event(leon_decoder* d)
         return e;
     }
     hipEvent_t e = nullptr;
-    hipEventCreate(&e);
+    hipError_t rc = hipEventCreate(&e);
+    if (rc != hipSuccess) {
+        fail(LEON_ERR_HIP, "hipEventCreate: %s", hipGetErrorString(rc));
+        return nullptr;
+    }
     return e;
+}
+
+// both events of a timed launch, or LEON_ERR_HIP with nothing leaked
+int get_event_pair(leon_decoder* d, hipEvent_t& a, hipEvent_t& b)
+{
+    a = get_event(d);
+    if (!a) return LEON_ERR_HIP;
+    b = get_event(d);
+    if (!b) {
+        d->ev_pool.push_back(a);
+        a = nullptr;
+        return LEON_ERR_HIP;
+    }
+    return LEON_OK;
 }
 
 void upload_tables(leon_decoder* d)
@@ -171,6 +199,35 @@ void upload_tables(leon_decoder* d)
 }
 
 int n_groups_of(const Geom& G) { return 2 * G.tasksY + 2 * G.tasksC; }
+
+// Algorithmic bytes of one picture's reconstruction (dense boundary) from its own maps.  Maps in
+// device memory are read back (synchronously: only prepared batches and timed ad-hoc submits ask).
+int algo_bytes_of(leon_decoder* d, const leon_picture& p, bool device_maps, double& bytes)
+{
+    const size_t mbs = (size_t)d->geom.mbw * d->geom.mbh;
+    if (p.type == LEON_PIC_I) {
+        bytes = kBytesI * (double)mbs;
+        return LEON_OK;
+    }
+    std::vector<uint8_t> rep(mbs), dir;
+    const uint8_t *rp = p.repadd, *dp = p.mb_dir;
+    if (device_maps) {
+        HIP_TRY(hipMemcpy(rep.data(), p.repadd, mbs, hipMemcpyDefault));
+        rp = rep.data();
+        if (p.type == LEON_PIC_B) {
+            dir.resize(mbs);
+            HIP_TRY(hipMemcpy(dir.data(), p.mb_dir, mbs, hipMemcpyDefault));
+            dp = dir.data();
+        }
+    }
+    uint64_t refs = 0;
+    for (size_t i = 0; i < mbs; i++) {
+        if (rp[i] >= 128) continue;                                    // replace: no prediction
+        refs += p.type == LEON_PIC_P ? 1u : (uint64_t)((dp[i] & 1) + ((dp[i] >> 1) & 1));
+    }
+    bytes = (p.type == LEON_PIC_P ? kBytesPBase : kBytesBBase) * (double)mbs + kBytesRef * (double)refs;
+    return LEON_OK;
+}
 
 int check_pic(const leon_decoder* d, const AnyPic& a)
 {
@@ -230,7 +287,7 @@ int guard_pending_conversions(leon_decoder* d, const int32_t* out_slots, int n)
 }
 
 // one launch of the type-specialised kernel over n pictures of that type
-int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, bool sparse = false, uint64_t entries = 0)
+int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, double dense_bytes, bool sparse = false, uint64_t entries = 0)
 {
     Geom G = d->geom;
     G.n_pics = n;
@@ -241,16 +298,16 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
     G.n_wg = (int)wgs;
     TimedLaunch tl{};
     if (d->timing) {
-        tl.a = get_event(d);
-        tl.b = get_event(d);
+        if (get_event_pair(d, tl.a, tl.b) != LEON_OK) return LEON_ERR_HIP;
         tl.kind = 0;
         tl.pic_type = type;
         tl.mbs = (uint64_t)d->geom.mbw * d->geom.mbh * (uint64_t)n;
-        tl.bytes = algo_bytes_per_mb(type) * (double)tl.mbs;
+        tl.bytes = dense_bytes;
         if (sparse)   // the lists replace the 768 B/MB of dense coefficients
             tl.bytes += 4.0 * (double)entries + 4.0 * (double)(n_groups_of(d->geom) + 1) * n - 768.0 * (double)tl.mbs;
         HIP_TRY(hipEventRecord(tl.a, d->stream));
     }
+    static_assert(64 * kWavesPerWG <= kReconMaxThreads, "k_recon is launched with more threads than its __launch_bounds__");
     const dim3 grid(G.n_wg), block(64 * kWavesPerWG);
     // LEON_DEBUG_LDS_PAD (bytes): extra dynamic LDS per workgroup = an occupancy throttle for experiments
     static const size_t lds_pad = getenv("LEON_DEBUG_LDS_PAD") ? (size_t)atol(getenv("LEON_DEBUG_LDS_PAD")) : 0;
@@ -273,7 +330,7 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
 }
 
 // descriptors sorted by type ([I..][P..][B..]); one launch per type present
-int launch_recon(leon_decoder* d, const PicDesc* d_descs, const int count[3], bool sparse = false, const uint64_t* entries = nullptr)
+int launch_recon(leon_decoder* d, const PicDesc* d_descs, const int count[3], const double bytes[3], bool sparse = false, const uint64_t* entries = nullptr)
 {
     // B pictures first, anchors last: what the NEXT batch will read as references (I and P planes)
     // is then the most recently written data and still sits in the 256 MB Infinity Cache / L2,
@@ -281,7 +338,7 @@ int launch_recon(leon_decoder* d, const PicDesc* d_descs, const int count[3], bo
     const int at[3] = {0, count[0], count[0] + count[1]};
     for (int k = 2; k >= 0; k--) {
         if (count[k] > 0) {
-            int rc = launch_recon_type(d, k + 1, d_descs + at[k], count[k], sparse, entries ? entries[k] : 0);
+            int rc = launch_recon_type(d, k + 1, d_descs + at[k], count[k], bytes[k], sparse, entries ? entries[k] : 0);
             if (rc != LEON_OK) return rc;
         }
     }
@@ -328,6 +385,9 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
     *out = nullptr;
     if (cfg->coded_width <= 0 || cfg->coded_height <= 0 || (cfg->coded_width & 15) || (cfg->coded_height & 15))
         return fail(LEON_ERR_INVALID, "coded size %dx%d must be positive multiples of 16", cfg->coded_width, cfg->coded_height);
+    // the format's size fields are 12 bits (decoders/jsv.js:491-500): coded sizes end at 4096
+    if (cfg->coded_width > 4096 || cfg->coded_height > 4096)
+        return fail(LEON_ERR_INVALID, "coded size %dx%d exceeds the format's 4096x4096", cfg->coded_width, cfg->coded_height);
     if (cfg->frame_width <= 0 || cfg->frame_height <= 0 || cfg->frame_width > cfg->coded_width || cfg->frame_height > cfg->coded_height)
         return fail(LEON_ERR_INVALID, "frame size %dx%d", cfg->frame_width, cfg->frame_height);
     if (cfg->n_slots < 1) return fail(LEON_ERR_INVALID, "n_slots %d", cfg->n_slots);
@@ -537,30 +597,52 @@ int submit_picture_any(leon_decoder* d, const AnyPic& pic)
     rc = guard_pending_conversions(d, &dp.p.out_slot, 1);
     if (rc != LEON_OK) return rc;
     HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc), hipMemcpyHostToDevice, d->stream));
-    rc = launch_recon_type(d, type, d->d_desc_ring + at, 1, pic.sparse, pic.n_entries);
+    double bytes = 0;
+    if (d->timing) {
+        rc = algo_bytes_of(d, pic.p, false, bytes);
+        if (rc != LEON_OK) return rc;
+    }
+    rc = launch_recon_type(d, type, d->d_desc_ring + at, 1, bytes, pic.sparse, pic.n_entries);
     if (rc != LEON_OK) return rc;
     HIP_TRY(hipEventRecord(s.done, d->stream));
     s.busy = true;
     return LEON_OK;
 }
 
-int check_batch(const leon_decoder* d, const AnyPic* pics, int n)
+// The pictures of one batch run in the same launches and must be mutually independent: no two write
+// the same slot, none reads a slot another one writes.  O(n) for any n: the slots written by the batch
+// are stamped in a per-decoder table (stamp = picture index + 1 under a fresh epoch), then every
+// reference is looked up in it.
+int check_batch(leon_decoder* d, const AnyPic* pics, int n)
 {
     for (int i = 0; i < n; i++) {
         int rc = check_pic(d, pics[i]);
         if (rc != LEON_OK) return rc;
     }
-    if (n <= 64)   // pictures of one launch must be mutually independent (O(n^2): small batches only)
-        for (int i = 0; i < n; i++)
-            for (int j = 0; j < i; j++) {
-                const leon_picture &a = pics[j].p, &b = pics[i].p;
-                if (a.out_slot == b.out_slot ||
-                    (b.type != LEON_PIC_I && b.ref_fwd_slot == a.out_slot) ||
-                    (b.type == LEON_PIC_B && b.ref_bwd_slot == a.out_slot) ||
-                    (a.type != LEON_PIC_I && a.ref_fwd_slot == b.out_slot) ||
-                    (a.type == LEON_PIC_B && a.ref_bwd_slot == b.out_slot))
-                    return fail(LEON_ERR_INVALID, "pictures %d and %d of one batch depend on each other", j, i);
-            }
+    if (d->writer_epoch.size() != (size_t)d->cfg.n_slots) {
+        d->writer_epoch.assign(d->cfg.n_slots, 0);
+        d->writer_of.assign(d->cfg.n_slots, 0);
+        d->epoch = 0;
+    }
+    if (++d->epoch == 0) {                       // wrapped after 2^32 batches: start over
+        std::fill(d->writer_epoch.begin(), d->writer_epoch.end(), 0u);
+        d->epoch = 1;
+    }
+    for (int i = 0; i < n; i++) {
+        const int s = pics[i].p.out_slot;
+        if (d->writer_epoch[s] == d->epoch)
+            return fail(LEON_ERR_INVALID, "pictures %d and %d of one batch depend on each other (both write slot %d)", d->writer_of[s], i, s);
+        d->writer_epoch[s] = d->epoch;
+        d->writer_of[s] = i;
+    }
+    for (int i = 0; i < n; i++) {
+        const leon_picture& p = pics[i].p;
+        const int refs[2] = {p.type != LEON_PIC_I ? p.ref_fwd_slot : -1, p.type == LEON_PIC_B ? p.ref_bwd_slot : -1};
+        for (int r : refs)
+            if (r >= 0 && d->writer_epoch[r] == d->epoch)
+                return fail(LEON_ERR_INVALID, "pictures %d and %d of one batch depend on each other (picture %d reads slot %d)",
+                            d->writer_of[r], i, i, r);
+    }
     return LEON_OK;
 }
 
@@ -588,8 +670,16 @@ int submit_batch_any(leon_decoder* d, const AnyPic* pics, int n, int mem)
     int count[3];
     uint64_t entries[3];
     sorted_descs(d, pics, n, d->h_desc_pinned + at, count, entries);
+    double bytes[3] = {0, 0, 0};
+    if (d->timing)   // a measurement mode: the maps are read back to price the launches
+        for (int i = 0; i < n; i++) {
+            double b = 0;
+            rc = algo_bytes_of(d, pics[i].p, true, b);
+            if (rc != LEON_OK) return rc;
+            bytes[pics[i].p.type - 1] += b;
+        }
     HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc) * n, hipMemcpyHostToDevice, d->stream));
-    return launch_recon(d, d->d_desc_ring + at, count, pics[0].sparse, entries);
+    return launch_recon(d, d->d_desc_ring + at, count, bytes, pics[0].sparse, entries);
 }
 
 int batch_create_any(leon_decoder* d, const AnyPic* pics, int n, leon_batch** out)
@@ -597,15 +687,22 @@ int batch_create_any(leon_decoder* d, const AnyPic* pics, int n, leon_batch** ou
     HIP_TRY(hipSetDevice(d->dev));
     *out = nullptr;
     std::vector<PicDesc> h(n);
-    for (int i = 0; i < n; i++) {
-        int rc = check_pic(d, pics[i]);
-        if (rc != LEON_OK) return rc;
-    }
+    int rc = check_batch(d, pics, n);
+    if (rc != LEON_OK) return rc;
     leon_batch* b = new (std::nothrow) leon_batch();
     if (!b) return fail(LEON_ERR_NOMEM, "out of host memory");
     b->n = n;
     b->sparse = pics[0].sparse;
     sorted_descs(d, pics, n, h.data(), b->count, b->entries_of_type);
+    for (int i = 0; i < n; i++) {
+        double pb = 0;
+        rc = algo_bytes_of(d, pics[i].p, true, pb);
+        if (rc != LEON_OK) {
+            delete b;
+            return rc;
+        }
+        b->bytes_of_type[pics[i].p.type - 1] += pb;
+    }
     b->out_slots.resize(n);
     for (int i = 0; i < n; i++) b->out_slots[i] = pics[i].p.out_slot;
     if (hipMalloc(&b->d_descs, sizeof(PicDesc) * n) != hipSuccess) {
@@ -670,7 +767,7 @@ int leon_batch_run(leon_decoder* d, const leon_batch* b)
     HIP_TRY(hipSetDevice(d->dev));
     int rc = guard_pending_conversions(d, b->out_slots.data(), b->n);
     if (rc != LEON_OK) return rc;
-    return launch_recon(d, b->d_descs, b->count, b->sparse, b->entries_of_type);
+    return launch_recon(d, b->d_descs, b->count, b->bytes_of_type, b->sparse, b->entries_of_type);
 }
 
 void leon_batch_destroy(leon_decoder* d, leon_batch* b)
@@ -724,8 +821,7 @@ int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, vo
     }
     TimedLaunch tl{};
     if (d->timing) {
-        tl.a = get_event(d);
-        tl.b = get_event(d);
+        if (get_event_pair(d, tl.a, tl.b) != LEON_OK) return LEON_ERR_HIP;
         tl.kind = 1;
         tl.mbs = (uint64_t)d->geom.mbw * d->geom.mbh * n;
         tl.bytes = kRgbaBytesPerMb * (double)tl.mbs;
@@ -734,16 +830,20 @@ int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, vo
     if (flavour == LEON_RGB_CPU_TWIN) {
         if ((G.fw & 1) || (G.fh & 1)) {   // bytes the quad loop never reaches stay 255 (fillArray)
             size_t nd = (size_t)G.fw * G.fh * n;
-            hipLaunchKernelGGL(k_fill255, dim3((unsigned)((nd + 255) / 256)), dim3(256), 0, cs, (uint32_t*)rgba_device, nd);
+            hipLaunchKernelGGL(k_fill255, dim3((unsigned)((nd + kRgbaBlock - 1) / kRgbaBlock)), dim3(kRgbaBlock), 0, cs, (uint32_t*)rgba_device, nd);
         }
-        if (G.cols > 0 && G.rows > 0 && (G.fw & 3) == 0 && ((size_t)rgba_device & 15) == 0)
-            hipLaunchKernelGGL(k_rgba_twin4, dim3(((unsigned)(G.fw / 4) * (unsigned)G.rows + 255) / 256, 1, n), dim3(256), 0, cs,
+        // k_rgba_twin4 divides by multiply-high, exact while idx * cols4 < 2^32 (idx < cols4 * rows);
+        // larger frames take the generic kernel (leon_create caps the coded size at 4096, which stays inside)
+        const uint64_t c4 = (uint64_t)(G.fw >> 2);
+        const bool twin4_exact = c4 * c4 * (uint64_t)G.rows < (1ull << 32);
+        if (G.cols > 0 && G.rows > 0 && (G.fw & 3) == 0 && ((size_t)rgba_device & 15) == 0 && twin4_exact)
+            hipLaunchKernelGGL(k_rgba_twin4, dim3(((unsigned)(G.fw / 4) * (unsigned)G.rows + kRgbaBlock - 1) / kRgbaBlock, 1, n), dim3(kRgbaBlock), 0, cs,
                                d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
         else if (G.cols > 0 && G.rows > 0)
-            hipLaunchKernelGGL(k_rgba_twin, dim3((G.cols + 255) / 256, G.rows, n), dim3(256), 0, cs,
+            hipLaunchKernelGGL(k_rgba_twin, dim3((G.cols + kRgbaBlock - 1) / kRgbaBlock, G.rows, n), dim3(kRgbaBlock), 0, cs,
                                d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
     } else {
-        hipLaunchKernelGGL(k_rgba_gl, dim3((G.fw + 255) / 256, G.fh, n), dim3(256), 0, cs,
+        hipLaunchKernelGGL(k_rgba_gl, dim3((G.fw + kRgbaBlock - 1) / kRgbaBlock, G.fh, n), dim3(kRgbaBlock), 0, cs,
                            d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
     }
     HIP_TRY(hipGetLastError());
@@ -904,10 +1004,10 @@ int leon_measure_copy_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, do
     hipEventCreate(&a);
     hipEventCreate(&b);
     size_t n = bytes / 16;
-    unsigned grid = (unsigned)((n + 255) / 256);
-    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, d->stream, src, dst, n);   // warm-up
+    unsigned grid = (unsigned)((n + kRgbaBlock - 1) / kRgbaBlock);
+    hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(kRgbaBlock), 0, d->stream, src, dst, n);   // warm-up
     hipEventRecord(a, d->stream);
-    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(256), 0, d->stream, src, dst, n);
+    for (int i = 0; i < iters; i++) hipLaunchKernelGGL(k_copy16, dim3(grid), dim3(kRgbaBlock), 0, d->stream, src, dst, n);
     hipEventRecord(b, d->stream);
     hipError_t e = hipStreamSynchronize(d->stream);
     float ms = 0;

@@ -77,6 +77,11 @@ struct Tables {                  // T6, per sequence
 };
 
 static constexpr int kWavesPerWG = 4;
+// Launch block sizes and the kernels' __launch_bounds__ come from the same constants: a launch with
+// more threads than the bound fails at launch time ("unspecified launch failure" from
+// hipGetLastError -- what a 512-thread block-size sweep of the RGBA kernels ran into in round 1).
+static constexpr int kReconMaxThreads = 256;
+static constexpr int kRgbaBlock = 256;
 static constexpr int kLdsCoef = 1024;            // 8 rows x 128 B of int16
 static constexpr int kLdsHandoffPitch = 288;     // 8 rows x 32 B + 32 B skew per block (bank spread)
 static constexpr int kLdsHandoff = 8 * kLdsHandoffPitch;
@@ -402,8 +407,11 @@ __device__ __forceinline__ int clamp_med3(int v, int hi)      // min(max(v, 0), 
     return d;
 }
 
+// `use` = this lane's macroblock predicts from this reference at all (B pictures: direction map);
+// a lane that does not carries the out-of-range offset: no cache access, zeros come back, and
+// recon_task() replaces the unused predictor by the other one.
 __device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, int W, int H, int y,
-                                              int px, int ay, int oh, int ov, bool in_pic, bool last_row)
+                                              int px, int ay, int oh, int ov, bool in_pic, bool last_row, bool use)
 {
     const int yy = y + ay;
     const uint32_t r0 = (uint32_t)__mul24(clamp_med3(yy, H - 1), W);
@@ -417,8 +425,8 @@ __device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, in
         uint32_t xo = (uint32_t)px & ~3u;
         // buffer loads: wave-uniform descriptor in SGPRs + 32-bit offset, no 64-bit address math
         const __amdgpu_buffer_rsrc_t rs = buf_rsrc((const void*)ref);
-        const v3u a = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(r0 + xo), 0, 0);
-        const v3u c = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(last_row && ov ? r1 + xo : kOobBit), 0, 0);
+        const v3u a = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(use ? r0 + xo : kOobBit), 0, 0);
+        const v3u c = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(use && last_row && ov ? r1 + xo : kOobBit), 0, 0);
         R.l0 = a.x; R.l1 = a.y; R.l2 = a.z;
         R.m0 = c.x; R.m1 = c.y; R.m2 = c.z;
     } else {                                         // vector leaves the picture (rare)
@@ -553,8 +561,9 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             useb = (dir & 2) != 0;
             nopred = nopred || dir == 0;
             // predictor A always reads the forward reference, B the backward one (scalar bases,
-            // 32-bit offsets); an unused direction fetches with a zero vector and is replaced by
-            // the other predictor afterwards: (p + p + 1) >> 1 == p
+            // 32-bit offsets); an unused direction fetches nothing (out-of-range offset in
+            // fetch_rows; its vector is zeroed so that the in-picture fast path is taken) and is
+            // replaced by the other predictor afterwards: (p + p + 1) >> 1 == p
             if (!usef) mf = 0;                                // both components at once
             if (!useb) mk = 0;
         }
@@ -571,6 +580,11 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             inB = (uint32_t)pxB < (uint32_t)(W - 7 - ohB);
         }
     }
+    // lanes that take nothing from a reference: the direction map says so (B), or the macroblock is
+    // not predicted at all (RepAdd / no direction).  They fetch nothing, and never take the slow path.
+    const bool useA = usef && !nopred, useB = useb && !nopred;
+    inA = inA || !useA;
+    inB = inB || !useB;
     const v2u msel = ia ? mI : mN;
     uint32_t qv = (uint32_t)q;
     int nim = ia ? 0 : -1;
@@ -593,15 +607,15 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     // B pictures: a wave whose macroblocks all predict from one side only (the leading pictures of
     // a closed GOP, runs of forward- or backward-only macroblocks) neither fetches nor interpolates
     // the other reference.  Wave-uniform, so it costs two scalar tests.
-    const bool any_f = TYPE != 3 || __builtin_amdgcn_ballot_w64(usef) != 0;
-    const bool any_b = TYPE == 3 && __builtin_amdgcn_ballot_w64(useb) != 0;
+    const bool any_f = TYPE != 3 || __builtin_amdgcn_ballot_w64(useA) != 0;
+    const bool any_b = TYPE == 3 && __builtin_amdgcn_ballot_w64(useB) != 0;
     if (TYPE != 1) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int Rh = CHROMA ? Rt : 2 * Rt + h;
             const uint32_t po = CHROMA ? (h == 0 ? ysz : ysz + (ysz >> 2)) : 0u;
-            if (any_f) rfh[h] = fetch_rows(gptr(pd.ref_fwd) + po, W, H, 8 * Rh + hi3, pxA, ayA, ohA, ovA, inA, hi3 == 7);
-            if (TYPE == 3 && any_b) rbh[h] = fetch_rows(gptr(pd.ref_bwd) + po, W, H, 8 * Rh + hi3, pxB, ayB, ohB, ovB, inB, hi3 == 7);
+            if (any_f) rfh[h] = fetch_rows(gptr(pd.ref_fwd) + po, W, H, 8 * Rh + hi3, pxA, ayA, ohA, ovA, inA, hi3 == 7, useA);
+            if (TYPE == 3 && any_b) rbh[h] = fetch_rows(gptr(pd.ref_bwd) + po, W, H, 8 * Rh + hi3, pxB, ayB, ohB, ovB, inB, hi3 == 7, useB);
         }
     }
 #pragma unroll
@@ -784,7 +798,7 @@ __device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G,
 // by the two predictors of the B path (VGPRs decide waves per SIMD), and a launch only ever
 // contains pictures of one type.
 template <int TYPE, bool SPARSE>
-__global__ __launch_bounds__(256) void k_recon(const PicDesc* __restrict__ descs, Geom G,
+__global__ __launch_bounds__(kReconMaxThreads) void k_recon(const PicDesc* __restrict__ descs, Geom G,
                                                const Tables* __restrict__ T)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -820,7 +834,7 @@ __device__ __forceinline__ uint32_t u8_clamped(double x)
 // CPU twin, one thread per 2x2 quad, with the reference's flat index progression
 // (player/easybits.player.js:2692-2782): identical to a plain crop for even frame
 // widths, and reproducing its one-sample-per-row-pair drift for odd ones.
-__global__ __launch_bounds__(256) void k_rgba_twin(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
+__global__ __launch_bounds__(kRgbaBlock) void k_rgba_twin(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
                                                    uint8_t* __restrict__ rgba, RgbaGeom G)
 {
     const int col = blockIdx.x * blockDim.x + threadIdx.x;
@@ -860,7 +874,7 @@ __global__ __launch_bounds__(256) void k_rgba_twin(const uint8_t* __restrict__ s
 // 4 x 2 pixels = two 2x2 quads, same fp64 operations in the same order as k_rgba_twin.  The 64 lanes
 // of a wave store 1 KB of contiguous RGBA per row with one 16-byte store each -- 5.8 TB/s; the
 // 8 x 2 form (two 16-byte stores per lane and row, lanes 32 bytes apart) reached 5.4.
-__global__ __launch_bounds__(256) void k_rgba_twin4(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
+__global__ __launch_bounds__(kRgbaBlock) void k_rgba_twin4(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
                                                     uint8_t* __restrict__ rgba, RgbaGeom G)
 {
     // one thread per (row pair, group of 4 columns), numbered linearly through the frame: a 1920-wide
@@ -903,14 +917,14 @@ __global__ __launch_bounds__(256) void k_rgba_twin4(const uint8_t* __restrict__ 
 }
 
 // fills what the quad loop never writes (odd last row / column, drift leftovers) with 255
-__global__ __launch_bounds__(256) void k_fill255(uint32_t* __restrict__ p, size_t n_dwords)
+__global__ __launch_bounds__(kRgbaBlock) void k_fill255(uint32_t* __restrict__ p, size_t n_dwords)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n_dwords) p[i] = 0xffffffffu;
 }
 
 // GL flavour: every pixel of the frame_w x frame_h crop, fp32, left-to-right, no contraction
-__global__ __launch_bounds__(256) void k_rgba_gl(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
+__global__ __launch_bounds__(kRgbaBlock) void k_rgba_gl(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
                                                  uint8_t* __restrict__ rgba, RgbaGeom G)
 {
     const int x = blockIdx.x * blockDim.x + threadIdx.x;
@@ -944,7 +958,7 @@ __global__ __launch_bounds__(256) void k_rgba_gl(const uint8_t* __restrict__ slo
 // ---- measured HBM roofline -----------------------------------------------------------
 // One 16-byte element per thread, no loop: the fastest of the copy shapes probed on MI355X
 // (tools/probe/bw_probe.cpp: 6.3 TB/s vs 4.8-5.9 TB/s for grid-stride forms).
-__global__ __launch_bounds__(256) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n)
+__global__ __launch_bounds__(kRgbaBlock) void k_copy16(const uint4* __restrict__ src, uint4* __restrict__ dst, size_t n)
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];

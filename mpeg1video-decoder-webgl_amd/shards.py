@@ -74,6 +74,32 @@ def shard_gops(index, rank, world):
     return [g for g in range(index["n_gops"]) if g % world == rank]
 
 
+def _splitmix64(x):
+    x = (x + 0x9E3779B97F4A7C15) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 30)) * 0xBF58476D1CE4E5B9) & 0xFFFFFFFFFFFFFFFF
+    x = ((x ^ (x >> 27)) * 0x94D049BB133111EB) & 0xFFFFFFFFFFFFFFFF
+    return x ^ (x >> 31)
+
+
+def gop_content(seed, gop_id, n_unique):
+    """What GOP `gop_id` of a synthetic stream carries: a pure function of seed ^ gop_id, so that
+    any rank -- or a single-rank run -- decoding the same GOP id decodes the same pictures.
+    Returns (index of the synthetic GOP body among the n_unique generated ones, 56-bit key of the
+    per-GOP variation applied on top, see gop_variation)."""
+    h = _splitmix64((int(seed) ^ int(gop_id)) & 0xFFFFFFFFFFFFFFFF)
+    return int(h % n_unique), int(h >> 8)
+
+
+def gop_variation(key, n_mb, n=16):
+    """The per-GOP variation: n macroblocks of the GOP's I picture get another quantiser scale
+    (positions and values from the key).  Cheap to apply to a cloned map on the device, changes
+    the decoded I picture and -- through prediction -- every picture of the GOP.
+    Returns (macroblock indices int64[n], quantiser scales uint8[n])."""
+    idx = np.array([_splitmix64(key + 2 * k + 1) % n_mb for k in range(n)], dtype=np.int64)
+    val = np.array([1 + _splitmix64(key ^ (0xABCD + k)) % 31 for k in range(n)], dtype=np.uint8)
+    return idx, val
+
+
 def gather_checksums(local, dist, torch):
     """All-gather of this rank's per-GOP checksums (int64 vector) -> [world][n_local]."""
     if dist is None or not dist.is_initialized() or dist.get_world_size() == 1:

@@ -86,9 +86,19 @@ def clip_vectors(mv, mbw, mbh, cw, ch, margin=1):
     return mv.reshape(-1).astype(np.int16)
 
 
+def _vectors(rng, mbw, mbh, mv_range, coherent):
+    """per-macroblock (H, V) vectors, uniform in +-mv_range half-pel; coherent = k > 1: one vector
+    per k x k macroblocks (a motion field, the way real content moves) instead of one per macroblock"""
+    if coherent <= 1:
+        return rng.integers(-mv_range, mv_range + 1, size=mbw * mbh * 2).astype(np.int16)
+    gh, gw = -(-mbh // coherent), -(-mbw // coherent)
+    coarse = rng.integers(-mv_range, mv_range + 1, size=(gh, gw, 2)).astype(np.int16)
+    return np.repeat(np.repeat(coarse, coherent, axis=0), coherent, axis=1)[:mbh, :mbw].reshape(-1).copy()
+
+
 def make_picture(rng, cw, ch, ptype, mv_range=31, in_picture=True, qm_intra=DEFAULT_INTRA_QUANT,
                  qm_non=DEFAULT_NON_INTRA_QUANT, intra_frac=0.10, skip_frac=0.15, uncoded_frac=0.3,
-                 force_dir=None):
+                 force_dir=None, mv_coherent=1):
     """Boundary tensors of one picture.  Returns a dict of numpy arrays."""
     mbw, mbh = cw // 16, ch // 16
     nmb = mbw * mbh
@@ -102,8 +112,8 @@ def make_picture(rng, cw, ch, ptype, mv_range=31, in_picture=True, qm_intra=DEFA
         intra = np.where(u < intra_frac, 255, 0).astype(np.uint8)
         skipped = (u >= intra_frac) & (u < intra_frac + skip_frac)
         t["repadd"] = intra.copy()
-        mv = rng.integers(-mv_range, mv_range + 1, size=nmb * 2).astype(np.int16)
-        mvb = rng.integers(-mv_range, mv_range + 1, size=nmb * 2).astype(np.int16)
+        mv = _vectors(rng, mbw, mbh, mv_range, mv_coherent)
+        mvb = _vectors(rng, mbw, mbh, mv_range, mv_coherent)
         if ptype == PIC_P:
             mv.reshape(-1, 2)[skipped] = 0           # skipped P macroblocks reset the vector (jsv.js:754-778)
         if in_picture:

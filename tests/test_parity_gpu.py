@@ -272,6 +272,44 @@ def test_argument_errors(L):
         dec.close()
 
 
+def test_batch_independence_is_checked_for_any_size(L):
+    """A picture that writes or reads a slot another picture of the same batch writes is refused --
+    for batches beyond 64 pictures and for prepared batches too (leon_batch_create), in O(n)."""
+    n = 200
+    dec = L.Decoder(32, 32, n_slots=n + 2)
+    try:
+        z = np.zeros((32, 32), np.int16)
+        zc = np.zeros((16, 16), np.int16)
+        m = np.zeros(4, np.uint8)
+        mv = np.zeros(8, np.int16)
+        keep = []
+        mk_i = lambda slot: L.make_picture(L.PIC_I, slot, z, zc, zc, m, m, keep=keep)
+        mk_p = lambda slot, ref: L.make_picture(L.PIC_P, slot, z, zc, zc, m, m, repadd=m, mv_fwd=mv, ref_fwd_slot=ref, keep=keep)
+        mk_b = lambda slot, f, b: L.make_picture(L.PIC_B, slot, z, zc, zc, m, m, repadd=m, mv_fwd=mv, mv_bwd=mv, mb_dir=m,
+                                                 ref_fwd_slot=f, ref_bwd_slot=b, keep=keep)
+        good = [mk_i(k) for k in range(n)]
+        dec.submit_batch(good, L.MEM_HOST)                       # independent: accepted
+        for bad_tail, what in (([mk_i(7)], "both write slot 7"),                    # duplicate output, far apart
+                               ([mk_p(n, 150)], "reads slot 150"),                  # P reads what picture 150 writes
+                               ([mk_b(n, n + 1, 199)], "reads slot 199")):          # B backward reference written in-batch
+            for call in (lambda pics: dec.submit_batch(pics, L.MEM_HOST), dec.batch_create):
+                with pytest.raises(L.LeonError) as e:
+                    call(good + bad_tail)
+                assert e.value.code == L.ERR_INVALID and "depend on each other" in str(e.value) and what in str(e.value), str(e.value)
+        # the anchor before the pictures that read it is the classic mistake: refused as well
+        with pytest.raises(L.LeonError):
+            dec.batch_create([mk_i(0), mk_p(1, 0)])
+        dec.sync()
+    finally:
+        dec.close()
+
+
+def test_coded_size_beyond_the_format_is_refused(L):
+    with pytest.raises(L.LeonError) as e:
+        L.Decoder(4112, 64)
+    assert "4096" in str(e.value)
+
+
 def test_device_batch_equals_single_submits_1080p(L, O, S):
     """Full-size property test: a device-resident batch of independent 1080p pictures
     gives the same planes as one-by-one host submits, and spot rows match the oracle."""

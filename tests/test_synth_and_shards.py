@@ -84,3 +84,69 @@ def test_two_rank_gloo_broadcast_of_stream_index(tmp_path):
     assert out.returncode == 0, out.stderr[-2000:]
     assert (tmp_path / "rank0.txt").read_text() == "[0, 2, 4, 6]"
     assert (tmp_path / "rank1.txt").read_text() == "[1, 3, 5]"
+
+
+_WORKER2 = r'''
+import os, sys, json
+sys.path[:0] = [os.path.join(%(root)r, "mpeg1video-decoder-webgl_amd")]
+import numpy as np, torch, torch.distributed as dist
+import shards
+dist.init_process_group("gloo")
+r, w = dist.get_rank(), dist.get_world_size()
+idx = shards.make_index(1920, 1088, 1920, 1080, 3, 10, 12) if r == 0 else None
+idx = shards.broadcast_index(idx, dist, torch, src=0)
+mine = shards.shard_gops(idx, r, w)
+def checksum(g):            # a decode-free stand-in for the RGBA checksum: a function of what the GOP carries
+    u, key = shards.gop_content(0x4C454F4E, g, 8)
+    i, v = shards.gop_variation(key, 8160)
+    return int(u * 1000003 + int(i.sum()) * 31 + int(v.astype(np.int64).sum()))
+sums = shards.gather_checksums([checksum(g) for g in mine], dist, torch)
+if r == 0:
+    by_gop = {}
+    for rr in range(w):
+        for g, v in zip(shards.shard_gops(idx, rr, w), sums[rr]):
+            by_gop[g] = v
+    json.dump({str(k): v for k, v in by_gop.items()}, open(os.path.join(%(out)r, "gathered.json"), "w"))
+dist.destroy_process_group()
+'''
+
+
+def test_rank_sharded_checksums_equal_a_single_rank_list(tmp_path):
+    """per-GOP checksums gathered from 2 ranks == the list one rank computes for the same GOP ids,
+    and GOP ids carry different content (what bench.py --gpus N relies on)"""
+    import json
+    import shards
+    script = tmp_path / "worker2.py"
+    script.write_text(_WORKER2 % {"root": ROOT, "out": str(tmp_path)})
+    out = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2",
+                          "--master-addr", "127.0.0.1", "--master-port", "29733", str(script)],
+                         env=dict(os.environ, MASTER_ADDR="127.0.0.1"), capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = {int(k): v for k, v in json.load(open(tmp_path / "gathered.json")).items()}
+
+    def checksum(g):
+        u, key = shards.gop_content(0x4C454F4E, g, 8)
+        i, v = shards.gop_variation(key, 8160)
+        return int(u * 1000003 + int(i.sum()) * 31 + int(v.astype(np.int64).sum()))
+    assert got == {g: checksum(g) for g in range(10)}
+    assert len(set(got.values())) == 10
+    bodies = {shards.gop_content(0x4C454F4E, g, 8)[0] for g in range(0, 128, 8)}
+    assert len(bodies) >= 4          # round-robin shards of 8 ranks still see several generated bodies
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4"], env=env, capture_output=True, text=True, timeout=120)
+    assert out.returncode != 0 and "--gpus 4 but WORLD_SIZE is 2" in out.stderr
+
+
+def test_coherent_motion_recipe():
+    import synth as S
+    t = S.make_picture(np.random.default_rng(3), 1920 // 4, 1088 // 4 // 16 * 16, S.PIC_B, mv_coherent=4)
+    mbw, mbh = 480 // 16, 1088 // 4 // 16
+    mv = t["mv_fwd"].reshape(mbh, mbw, 2)
+    same = (mv[:, 1:] == mv[:, :-1]).all(axis=2).mean()
+    assert same > 0.6          # neighbours mostly share their vector (edges are clipped per macroblock)
+    t = S.make_picture(np.random.default_rng(3), 480, 256, S.PIC_B)
+    mv = t["mv_fwd"].reshape(16, 30, 2)
+    assert (mv[:, 1:] == mv[:, :-1]).all(axis=2).mean() < 0.1
