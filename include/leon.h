@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define LEON_ABI_VERSION 1
+#define LEON_ABI_VERSION 2
 
 enum {
     LEON_OK = 0,
@@ -86,6 +86,15 @@ typedef struct leon_picture {
     const int16_t* mv_fwd; /* P, B */
     const int16_t* mv_bwd; /* B */
     const uint8_t* mb_dir; /* B */
+    /* Fused display conversion (ABI 2; optional, NULL = off).  rgba_out is a DEVICE pointer to
+     * frame_width*frame_height*4 bytes, 16-byte aligned: the reconstruction kernel itself converts the
+     * picture (= renderFrameGL / YCbCrToRGBA, player/easybits.player.js:2787-2858 / :2674-2785, the
+     * LEON_RGB_CPU_TWIN arithmetic) instead of a later leon_convert_rgba reading the planes back.
+     * Needs frame_width % 8 == 0.  no_planes != 0: the slot's planes are not written at all -- for a
+     * picture nobody predicts from (B pictures); out_slot must still be a valid slot and stays untouched. */
+    void*   rgba_out;
+    int32_t no_planes;
+    int32_t reserved;
 } leon_picture;
 
 /* The same picture with its coefficients as sparse per-group lists -- the format the native
@@ -104,6 +113,9 @@ typedef struct leon_sparse_picture {
     const int16_t* mv_fwd;
     const int16_t* mv_bwd;
     const uint8_t* mb_dir;
+    void*   rgba_out;          /* fused display conversion, as in leon_picture */
+    int32_t no_planes;
+    int32_t reserved2;
 } leon_sparse_picture;
 
 typedef struct leon_kernel_stats {

@@ -86,6 +86,7 @@ AnyPic any_of(const leon_sparse_picture& q)
     a.p.type = q.type; a.p.out_slot = q.out_slot; a.p.ref_fwd_slot = q.ref_fwd_slot; a.p.ref_bwd_slot = q.ref_bwd_slot;
     a.p.qscale = q.qscale; a.p.intra = q.intra; a.p.repadd = q.repadd;
     a.p.mv_fwd = q.mv_fwd; a.p.mv_bwd = q.mv_bwd; a.p.mb_dir = q.mb_dir;
+    a.p.rgba_out = q.rgba_out; a.p.no_planes = q.no_planes;
     a.grp_off = q.grp_off; a.entries = q.entries; a.n_entries = q.n_entries;
     a.sparse = true;
     return a;
@@ -101,13 +102,14 @@ struct Staging {                 // device copy of one host-submitted picture
 }  // namespace
 
 struct leon_batch {
-    PicDesc* d_descs = nullptr;   // sorted by picture type: [I..][P..][B..]
+    // descriptors sorted by launch class: class = type - 1 (planes only) or 3 + type - 1 (fused display conversion)
+    PicDesc* d_descs = nullptr;
     int n = 0;
-    int count[3] = {0, 0, 0};     // pictures of type I, P, B
+    int count[6] = {0, 0, 0, 0, 0, 0};
     std::vector<int32_t> out_slots;
     bool sparse = false;
-    uint64_t entries_of_type[3] = {0, 0, 0};   // sparse: list lengths per type (algorithmic bytes)
-    double bytes_of_type[3] = {0, 0, 0};       // dense-boundary algorithmic bytes per type, from the pictures' own maps
+    uint64_t entries_of_type[6] = {0, 0, 0, 0, 0, 0};   // sparse: list lengths per class (algorithmic bytes)
+    double bytes_of_type[6] = {0, 0, 0, 0, 0, 0};       // dense-boundary algorithmic bytes per class, from the pictures' own maps
 };
 
 struct leon_decoder {
@@ -205,8 +207,10 @@ int n_groups_of(const Geom& G) { return 2 * G.tasksY + 2 * G.tasksC; }
 int algo_bytes_of(leon_decoder* d, const leon_picture& p, bool device_maps, double& bytes)
 {
     const size_t mbs = (size_t)d->geom.mbw * d->geom.mbh;
+    // fused display conversion: + 1024 B of RGBA per macroblock, - the 384 B of planes when they are not written
+    const double disp = p.rgba_out ? (1024.0 - (p.no_planes ? 384.0 : 0.0)) * (double)mbs : 0.0;
     if (p.type == LEON_PIC_I) {
-        bytes = kBytesI * (double)mbs;
+        bytes = kBytesI * (double)mbs + disp;
         return LEON_OK;
     }
     std::vector<uint8_t> rep(mbs), dir;
@@ -225,7 +229,7 @@ int algo_bytes_of(leon_decoder* d, const leon_picture& p, bool device_maps, doub
         if (rp[i] >= 128) continue;                                    // replace: no prediction
         refs += p.type == LEON_PIC_P ? 1u : (uint64_t)((dp[i] & 1) + ((dp[i] >> 1) & 1));
     }
-    bytes = (p.type == LEON_PIC_P ? kBytesPBase : kBytesBBase) * (double)mbs + kBytesRef * (double)refs;
+    bytes = (p.type == LEON_PIC_P ? kBytesPBase : kBytesBBase) * (double)mbs + kBytesRef * (double)refs + disp;
     return LEON_OK;
 }
 
@@ -249,6 +253,10 @@ int check_pic(const leon_decoder* d, const AnyPic& a)
         if (!p.mv_bwd || !p.mb_dir) return fail(LEON_ERR_INVALID, "B picture without mv_bwd/mb_dir");
         if (p.ref_bwd_slot == p.out_slot) return fail(LEON_ERR_INVALID, "out_slot equals ref_bwd_slot");
     }
+    if (p.rgba_out) {
+        if (d->cfg.frame_width & 7) return fail(LEON_ERR_INVALID, "fused display conversion needs frame_width %% 8 == 0 (it is %d)", d->cfg.frame_width);
+        if ((size_t)p.rgba_out & 15) return fail(LEON_ERR_INVALID, "rgba_out must be 16-byte aligned");
+    } else if (p.no_planes) return fail(LEON_ERR_INVALID, "no_planes without rgba_out: the picture would leave nothing behind");
     return LEON_OK;
 }
 
@@ -271,6 +279,9 @@ void fill_desc(const leon_decoder* d, const AnyPic& a, PicDesc& o)
     o.ref_fwd = p.type != LEON_PIC_I ? d->d_slots + (size_t)p.ref_fwd_slot * d->slot_stride : nullptr;
     o.ref_bwd = p.type == LEON_PIC_B ? d->d_slots + (size_t)p.ref_bwd_slot * d->slot_stride : nullptr;
     o.type = p.type;
+    o.rgba = (uint8_t*)p.rgba_out;
+    o.no_planes = p.rgba_out ? p.no_planes : 0;
+    o.pad_ = 0;
 }
 
 // a submit that overwrites a slot still being converted on the second stream waits for it
@@ -287,10 +298,16 @@ int guard_pending_conversions(leon_decoder* d, const int32_t* out_slots, int n)
 }
 
 // one launch of the type-specialised kernel over n pictures of that type
-int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, double dense_bytes, bool sparse = false, uint64_t entries = 0)
+int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, double dense_bytes, bool sparse = false, uint64_t entries = 0,
+                      bool display = false)
 {
     Geom G = d->geom;
     G.n_pics = n;
+    if (display) {   // one task = one chroma group with everything above it (k_recon_display)
+        G.tasks_per_pic = G.tasksC;
+        G.wg_per_pic = (G.tasks_per_pic + kWavesPerWG - 1) / kWavesPerWG;
+        G.inv_wg_per_pic = G.wg_per_pic == 1 ? 0u : (uint32_t)(((1ull << 32) + G.wg_per_pic - 1) / G.wg_per_pic);
+    }
     long long wgs = (long long)n * G.wg_per_pic;
     // the kernel divides by multiply-high: exact while n_wg * wg_per_pic < 2^32
     if (wgs > 0x7fffffffLL || wgs * G.wg_per_pic >= (1LL << 32))
@@ -311,8 +328,18 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
     const dim3 grid(G.n_wg), block(64 * kWavesPerWG);
     // LEON_DEBUG_LDS_PAD (bytes): extra dynamic LDS per workgroup = an occupancy throttle for experiments
     static const size_t lds_pad = getenv("LEON_DEBUG_LDS_PAD") ? (size_t)atol(getenv("LEON_DEBUG_LDS_PAD")) : 0;
-    const size_t lds = kWavesPerWG * kLdsPerWave + lds_pad;
-    if (!sparse) {
+    const size_t lds = kWavesPerWG * (display ? kLdsPerWaveDisplay : kLdsPerWave) + lds_pad;
+    if (display) {
+        if (!sparse) {
+            if (type == LEON_PIC_I) hipLaunchKernelGGL((k_recon_display<1, false>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+            else if (type == LEON_PIC_P) hipLaunchKernelGGL((k_recon_display<2, false>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+            else hipLaunchKernelGGL((k_recon_display<3, false>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+        } else {
+            if (type == LEON_PIC_I) hipLaunchKernelGGL((k_recon_display<1, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+            else if (type == LEON_PIC_P) hipLaunchKernelGGL((k_recon_display<2, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+            else hipLaunchKernelGGL((k_recon_display<3, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+        }
+    } else if (!sparse) {
         if (type == LEON_PIC_I) hipLaunchKernelGGL((k_recon<1, false>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
         else if (type == LEON_PIC_P) hipLaunchKernelGGL((k_recon<2, false>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
         else hipLaunchKernelGGL((k_recon<3, false>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
@@ -329,33 +356,38 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
     return LEON_OK;
 }
 
-// descriptors sorted by type ([I..][P..][B..]); one launch per type present
-int launch_recon(leon_decoder* d, const PicDesc* d_descs, const int count[3], const double bytes[3], bool sparse = false, const uint64_t* entries = nullptr)
+// launch class of a picture: its type, and whether the display conversion is fused in
+inline int class_of(const leon_picture& p) { return (p.rgba_out ? 3 : 0) + p.type - 1; }
+
+// descriptors sorted by class; one launch per class present
+int launch_recon(leon_decoder* d, const PicDesc* d_descs, const int count[6], const double bytes[6], bool sparse = false, const uint64_t* entries = nullptr)
 {
     // B pictures first, anchors last: what the NEXT batch will read as references (I and P planes)
     // is then the most recently written data and still sits in the 256 MB Infinity Cache / L2,
     // instead of being pushed out by B planes nobody reads again.
-    const int at[3] = {0, count[0], count[0] + count[1]};
-    for (int k = 2; k >= 0; k--) {
+    int at[6];
+    for (int k = 0, a = 0; k < 6; k++) { at[k] = a; a += count[k]; }
+    static const int order[6] = {5, 2, 4, 1, 3, 0};
+    for (int k : order) {
         if (count[k] > 0) {
-            int rc = launch_recon_type(d, k + 1, d_descs + at[k], count[k], bytes[k], sparse, entries ? entries[k] : 0);
+            int rc = launch_recon_type(d, k % 3 + 1, d_descs + at[k], count[k], bytes[k], sparse, entries ? entries[k] : 0, k >= 3);
             if (rc != LEON_OK) return rc;
         }
     }
     return LEON_OK;
 }
 
-// fill `out` with the descriptors of pics sorted by type, and the per-type counts
-void sorted_descs(const leon_decoder* d, const AnyPic* pics, int n, PicDesc* out, int count[3], uint64_t entries[3])
+// fill `out` with the descriptors of pics sorted by class, and the per-class counts
+void sorted_descs(const leon_decoder* d, const AnyPic* pics, int n, PicDesc* out, int count[6], uint64_t entries[6])
 {
-    count[0] = count[1] = count[2] = 0;
-    entries[0] = entries[1] = entries[2] = 0;
+    for (int k = 0; k < 6; k++) { count[k] = 0; entries[k] = 0; }
     for (int i = 0; i < n; i++) {
-        count[pics[i].p.type - 1]++;
-        entries[pics[i].p.type - 1] += pics[i].n_entries;
+        count[class_of(pics[i].p)]++;
+        entries[class_of(pics[i].p)] += pics[i].n_entries;
     }
-    int at[3] = {0, count[0], count[0] + count[1]};
-    for (int i = 0; i < n; i++) fill_desc(d, pics[i], out[at[pics[i].p.type - 1]++]);
+    int at[6];
+    for (int k = 0, a = 0; k < 6; k++) { at[k] = a; a += count[k]; }
+    for (int i = 0; i < n; i++) fill_desc(d, pics[i], out[at[class_of(pics[i].p)]++]);
 }
 
 // reserve n consecutive descriptors in the ring (wrap = wait for the previous lap)
@@ -429,6 +461,8 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
     G.inv_wg_per_pic = G.wg_per_pic == 1 ? 0u : inv32((uint32_t)G.wg_per_pic);
     G.inv_gY = G.gY == 1 ? 0u : inv32((uint32_t)G.gY);
     G.inv_gC = G.gC == 1 ? 0u : inv32((uint32_t)G.gC);
+    G.fw = cfg->frame_width;
+    G.fh = cfg->frame_height;
     d->plane_bytes = (size_t)G.cw * G.ch * 3 / 2;
     d->slot_stride = (d->plane_bytes + 255) / 256 * 256 + 256;   // tail pad: the 12-byte MC window may over-read 3 bytes
     d->inuse.assign(cfg->n_slots, 0);
@@ -602,7 +636,7 @@ int submit_picture_any(leon_decoder* d, const AnyPic& pic)
         rc = algo_bytes_of(d, pic.p, false, bytes);
         if (rc != LEON_OK) return rc;
     }
-    rc = launch_recon_type(d, type, d->d_desc_ring + at, 1, bytes, pic.sparse, pic.n_entries);
+    rc = launch_recon_type(d, type, d->d_desc_ring + at, 1, bytes, pic.sparse, pic.n_entries, pic.p.rgba_out != nullptr);
     if (rc != LEON_OK) return rc;
     HIP_TRY(hipEventRecord(s.done, d->stream));
     s.busy = true;
@@ -667,16 +701,16 @@ int submit_batch_any(leon_decoder* d, const AnyPic* pics, int n, int mem)
         rc = guard_pending_conversions(d, outs.data(), n);
         if (rc != LEON_OK) return rc;
     }
-    int count[3];
-    uint64_t entries[3];
+    int count[6];
+    uint64_t entries[6];
     sorted_descs(d, pics, n, d->h_desc_pinned + at, count, entries);
-    double bytes[3] = {0, 0, 0};
+    double bytes[6] = {0, 0, 0, 0, 0, 0};
     if (d->timing)   // a measurement mode: the maps are read back to price the launches
         for (int i = 0; i < n; i++) {
             double b = 0;
             rc = algo_bytes_of(d, pics[i].p, true, b);
             if (rc != LEON_OK) return rc;
-            bytes[pics[i].p.type - 1] += b;
+            bytes[class_of(pics[i].p)] += b;
         }
     HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc) * n, hipMemcpyHostToDevice, d->stream));
     return launch_recon(d, d->d_desc_ring + at, count, bytes, pics[0].sparse, entries);
@@ -701,7 +735,7 @@ int batch_create_any(leon_decoder* d, const AnyPic* pics, int n, leon_batch** ou
             delete b;
             return rc;
         }
-        b->bytes_of_type[pics[i].p.type - 1] += pb;
+        b->bytes_of_type[class_of(pics[i].p)] += pb;
     }
     b->out_slots.resize(n);
     for (int i = 0; i < n; i++) b->out_slots[i] = pics[i].p.out_slot;

@@ -55,6 +55,9 @@ struct PicDesc {                 // one per picture of a batch, device resident
     uint32_t       n_entries;    // sparse boundary: entries[] length
     const uint32_t* grp_off;     // sparse boundary (include/leon_vlc.h): prefix offsets per 64x8 group
     const uint32_t* entries;     // (tile byte offset << 16) | level
+    uint8_t*       rgba;         // fused display conversion: frame_w x frame_h RGBA8 destination (else null)
+    int32_t        no_planes;    // with rgba: the slot's planes are not written (picture is never a reference)
+    int32_t        pad_;
 };
 
 struct Geom {
@@ -68,6 +71,7 @@ struct Geom {
     int32_t n_wg;                // grid size
     uint32_t inv_wg_per_pic;     // ceil(2^32 / wg_per_pic)
     uint32_t inv_gY, inv_gC;     // ceil(2^32 / gY), ceil(2^32 / gC)
+    int32_t fw, fh;              // display crop (fused display conversion)
     int32_t pad_;
 };
 
@@ -86,6 +90,12 @@ static constexpr int kLdsCoef = 1024;            // 8 rows x 128 B of int16
 static constexpr int kLdsHandoffPitch = 288;     // 8 rows x 32 B + 32 B skew per block (bank spread)
 static constexpr int kLdsHandoff = 8 * kLdsHandoffPitch;
 static constexpr int kLdsPerWave = kLdsCoef + kLdsHandoff;
+// fused display conversion: the Cb and Cr samples of the task's 8 macroblocks (8 rows x 64 bytes each)
+// wait in LDS for the luma parts of the same task
+static constexpr int kLdsStash = 2 * 512;
+// ... and the Y samples of a luma part's upper half wait for the lower half (8 rows x 64 bytes)
+static constexpr int kLdsYPark = 512;
+static constexpr int kLdsPerWaveDisplay = kLdsPerWave + kLdsStash + kLdsYPark;
 
 // ---- small helpers -----------------------------------------------------------
 
@@ -486,9 +496,46 @@ __device__ __forceinline__ uint32_t pred_x256(uint32_t pred)
 // Everything that depends only on the macroblock -- maps, vectors and their half-pel
 // decomposition, quantiser tables, the in-picture test -- is computed once per task.
 
-template <int TYPE, bool CHROMA, bool SPARSE>
+// Fused display conversion (DISPLAY): the picture leaves the kernel as RGBA8 as well -- the CPU twin of
+// the reference's conversion, same fp64 operations in the same order as k_rgba_twin4 below -- so the
+// planes of a picture nobody predicts from (B pictures: 8 of 12 in IBBP) are never written and never
+// read back, and the others are not read back.  A task then covers 8 macroblocks completely: first the
+// chroma part (CHROMA = true: the Cb and Cr groups, whose samples are parked in an LDS stash), then the
+// two luma parts (CHROMA = false, 4 macroblocks each), whose lanes hold 8 horizontally adjacent Y samples
+// and find their 4 Cb and 4 Cr samples in the stash.
+struct Display {
+    char* stash;                 // LDS: [Cb | Cr][8 rows][64 bytes]
+    int side;                    // luma parts: 0 / 1 = left / right four macroblocks of the chroma group
+};
+
+// Uint8ClampedArray store: clamp, round half to even (2^52+2^51 trick; |x| < 2^31)
+__device__ __forceinline__ uint32_t u8_clamped(double x);
+
+// 4 horizontally adjacent pixels: Y samples y4 (one packed dword), chroma samples cb2 / cr2 (one per
+// pixel pair, two packed bytes each) -> 4 RGBA dwords; the operations and their order are those of
+// k_rgba_twin4 (= the reference's YCbCrToRGBA, player/easybits.player.js:2692-2782)
+__device__ __forceinline__ v4u rgba_row4(uint32_t y4, uint32_t cb2, uint32_t cr2)
+{
+    uint32_t px[4];
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const double yuvr = (double)((cr2 >> (8 * q)) & 255u) - 128.0, yuvb = (double)((cb2 >> (8 * q)) & 255u) - 128.0;
+        const double r = yuvr * 1.59603;
+        const double g = (-0.81297 * yuvr) - (0.39176 * yuvb);
+        const double b = yuvb * 2.01723;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {
+            const int i = 2 * q + k;
+            const double ys = ((double)((y4 >> (8 * i)) & 255u) - 16.0) * 1.16438;
+            px[i] = u8_clamped(r + ys) | (u8_clamped(g + ys) << 8) | (u8_clamped(b + ys) << 16) | 0xff000000u;
+        }
+    }
+    return v4u{px[0], px[1], px[2], px[3]};
+}
+
+template <int TYPE, bool CHROMA, bool SPARSE, bool DISPLAY>
 __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, const Tables* __restrict__ Tg,
-                                           int Rt, int g, char* lds, int lane)
+                                           int Rt, int g, char* lds, int lane, Display dsp)
 {
     const int W = CHROMA ? G.cw >> 1 : G.cw;
     const int H = CHROMA ? G.ch >> 1 : G.ch;
@@ -762,8 +809,62 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         v2u o;
         o.x = sat_pk2(t[0], t[1], 8) | (sat_pk2(t[2], t[3], 8) << 16);
         o.y = sat_pk2(t[4], t[5], 8) | (sat_pk2(t[6], t[7], 8) << 16);
-        __builtin_amdgcn_raw_buffer_store_b64(o, buf_rsrc(pd.out + plane_off), (int)out_voff, (int)(half ? half_step : 0u), 0);
+        if constexpr (!DISPLAY) {
+            __builtin_amdgcn_raw_buffer_store_b64(o, buf_rsrc(pd.out + plane_off), (int)out_voff, (int)(half ? half_step : 0u), 0);
+        } else {
+            // planes only for pictures that will be predicted from (wave-uniform: a resource without records drops the store)
+            const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(pd.out + plane_off), 0, pd.no_planes ? 0 : 0x7fffffff, 0x00020000);
+            __builtin_amdgcn_raw_buffer_store_b64(o, prs, (int)out_voff, (int)(half ? half_step : 0u), 0);
+            if constexpr (CHROMA) {
+                // park the samples for the luma parts: [plane = half][row hi3][8 bytes of macroblock lo3]
+                *reinterpret_cast<v2u*>(dsp.stash + half * 512 + hi3 * 64 + lo3 * 8) = o;
+            } else {
+                // converted after both halves (stage 5): the upper half's rows wait behind the stash, the
+                // lower half's in the coefficient tile, which is free by then
+                *reinterpret_cast<v2u*>((half == 0 ? dsp.stash + kLdsStash : lds) + hi3 * 64 + lo3 * 8) = o;
+            }
+        }
         // the next half overwrites the LDS strip: order its writes behind this half's reads
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+    if constexpr (DISPLAY && !CHROMA) {
+        // ---- stage 5 (fused display conversion): RGBA of the 64 x 16 strip ---------------------------
+        // Done after both halves: nothing of the reconstruction is live any more (in place after each half
+        // the conversion's fp64 temporaries came on top of the next half's prefetched reference rows and cost
+        // the B path two waves of occupancy).  A lane holds samples 8b .. 8b+7 of row n of each half;
+        // converted as they lie, a store instruction would write 16-byte pieces 32 bytes apart (half-filled
+        // lines).  So the rows went through LDS (written at the end of each half, ordered by the fences
+        // there) and lane (n, b) converts pixels 4b .. 4b+3 and 32+4b .. 32+4b+3: every store instruction
+        // writes one full 128-byte line per row.
+        const int xa = 64 * g + 4 * lo3;                           // first pixel of the lane's left quad
+        const __amdgpu_buffer_rsrc_t rrs = buf_rsrc(pd.rgba);
+#pragma unroll
+        for (int half = 0; half < 2; half++) {
+            const int yrow = 8 * (2 * Rt + half) + hi3;
+            // chroma: row y>>1 = stash row 4*half + (n>>1); the quad's two chroma samples start at column
+            // xa/2 of the plane = 32*side + 2b within the chroma group; the right quad 16 columns further
+            const char* yp = (half == 0 ? dsp.stash + kLdsStash : lds) + hi3 * 64 + lo3 * 4;
+            const char* sp = dsp.stash + (4 * half + (hi3 >> 1)) * 64 + 32 * dsp.side + 2 * lo3;
+            const uint32_t ya = *reinterpret_cast<const uint32_t*>(yp), yb = *reinterpret_cast<const uint32_t*>(yp + 32);
+            const uint32_t cba = *reinterpret_cast<const uint16_t*>(sp), cra = *reinterpret_cast<const uint16_t*>(sp + 512);
+            const uint32_t cbb = *reinterpret_cast<const uint16_t*>(sp + 16), crb = *reinterpret_cast<const uint16_t*>(sp + 528);
+            // the frame is the top-left crop of the coded picture; its width is a multiple of 8 (host check)
+            const uint32_t row_off = (uint32_t)yrow * (uint32_t)G.fw;
+            const bool in_a = yrow < G.fh && xa < G.fw, in_b = yrow < G.fh && xa + 32 < G.fw;
+            // one quad after the other (scheduling barriers): the four quads interleaved for instruction-level
+            // parallelism need 93 registers on the B path = 5 waves per SIMD instead of 7
+            __builtin_amdgcn_sched_barrier(0);
+            const v4u pa = rgba_row4(ya, cba, cra);
+            __builtin_amdgcn_raw_buffer_store_b128(pa, rrs, (int)(((row_off + (uint32_t)xa) * 4u) | (in_a ? 0u : kOobBit)), 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+            const v4u pb = rgba_row4(yb, cbb, crb);
+            __builtin_amdgcn_raw_buffer_store_b128(pb, rrs, (int)(((row_off + (uint32_t)xa + 32u) * 4u) | (in_b ? 0u : kOobBit)), 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // the next part of the task reuses the strip
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -784,13 +885,14 @@ template <int TYPE, bool SPARSE>
 __device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G, const Tables* T,
                                                int t, char* lds, int lane)
 {
+    const Display none{nullptr, 0};
     if (t < G.tasksY) {
         int Rt = div_inv(t, G.inv_gY), g = t - Rt * G.gY;
-        recon_task<TYPE, false, SPARSE>(pd, G, T, Rt, g, lds, lane);
+        recon_task<TYPE, false, SPARSE, false>(pd, G, T, Rt, g, lds, lane, none);
     } else {
         t -= G.tasksY;
         int Rt = div_inv(t, G.inv_gC), g = t - Rt * G.gC;
-        recon_task<TYPE, true, SPARSE>(pd, G, T, Rt, g, lds, lane);
+        recon_task<TYPE, true, SPARSE, false>(pd, G, T, Rt, g, lds, lane, none);
     }
 }
 
@@ -810,6 +912,34 @@ __global__ __launch_bounds__(kReconMaxThreads) void k_recon(const PicDesc* __res
     if (t >= G.tasks_per_pic) return;
     char* lds = smem + wave * kLdsPerWave;
     recon_dispatch<TYPE, SPARSE>(descs[pic], G, T, t, lds, lane);
+}
+
+// The same reconstruction with the display conversion fused in (see Display above).  One wave = the 8
+// macroblocks of one chroma group, all components: tasks_per_pic = tasksC here (the host sets Geom up
+// for that), the chroma part first, then the left and the right luma part.
+template <int TYPE, bool SPARSE>
+__global__ __launch_bounds__(kReconMaxThreads) void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
+                                                                    const Tables* __restrict__ T)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane = threadIdx.x & 63;
+    const int wg = xcd_remap(blockIdx.x, G.n_wg);
+    const int pic = div_inv(wg, G.inv_wg_per_pic);
+    const int t = (wg - pic * G.wg_per_pic) * kWavesPerWG + wave;
+    if (t >= G.tasks_per_pic) return;
+    char* lds = smem + wave * kLdsPerWaveDisplay;
+    const PicDesc& pd = descs[pic];
+    const int Rt = div_inv(t, G.inv_gC), gc = t - Rt * G.gC;
+    Display dsp{lds + kLdsPerWave, 0};
+    recon_task<TYPE, true, SPARSE, true>(pd, G, T, Rt, gc, lds, lane, dsp);
+    // the two luma parts as two calls, not a loop: the loop form keeps 15 more registers live (B path: 93)
+    dsp.side = 0;
+    recon_task<TYPE, false, SPARSE, true>(pd, G, T, Rt, 2 * gc, lds, lane, dsp);
+    if (2 * gc + 1 < G.gY) {
+        dsp.side = 1;
+        recon_task<TYPE, false, SPARSE, true>(pd, G, T, Rt, 2 * gc + 1, lds, lane, dsp);
+    }
 }
 
 // ---- K3: YCbCr 4:2:0 -> RGBA8 ------------------------------------------------------

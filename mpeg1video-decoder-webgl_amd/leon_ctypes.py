@@ -47,14 +47,17 @@ class Picture(C.Structure):
                 ("ref_bwd_slot", C.c_int32), ("coef_y", C.c_void_p), ("coef_cb", C.c_void_p),
                 ("coef_cr", C.c_void_p), ("qscale", C.c_void_p), ("intra", C.c_void_p),
                 ("repadd", C.c_void_p), ("mv_fwd", C.c_void_p), ("mv_bwd", C.c_void_p),
-                ("mb_dir", C.c_void_p)]
+                ("mb_dir", C.c_void_p),
+                # ABI 2: fused display conversion (device pointer to the RGBA frame, or NULL)
+                ("rgba_out", C.c_void_p), ("no_planes", C.c_int32), ("reserved", C.c_int32)]
 
 
 class SparsePicture(C.Structure):
     _fields_ = [("type", C.c_int32), ("out_slot", C.c_int32), ("ref_fwd_slot", C.c_int32),
                 ("ref_bwd_slot", C.c_int32), ("grp_off", C.c_void_p), ("entries", C.c_void_p),
                 ("n_entries", C.c_uint32), ("reserved", C.c_int32), ("qscale", C.c_void_p), ("intra", C.c_void_p),
-                ("repadd", C.c_void_p), ("mv_fwd", C.c_void_p), ("mv_bwd", C.c_void_p), ("mb_dir", C.c_void_p)]
+                ("repadd", C.c_void_p), ("mv_fwd", C.c_void_p), ("mv_bwd", C.c_void_p), ("mb_dir", C.c_void_p),
+                ("rgba_out", C.c_void_p), ("no_planes", C.c_int32), ("reserved2", C.c_int32)]
 
 
 class KernelStats(C.Structure):
@@ -127,10 +130,14 @@ def _hostptr(a, dtype, keep):
 
 
 def make_picture(ptype, out_slot, coef_y, coef_cb, coef_cr, qscale, intra, repadd=None, mv_fwd=None,
-                 mv_bwd=None, mb_dir=None, ref_fwd_slot=-1, ref_bwd_slot=-1, keep=None, device=False):
-    """Fill a Picture from numpy arrays (host) or raw device addresses (device=True: ints)."""
+                 mv_bwd=None, mb_dir=None, ref_fwd_slot=-1, ref_bwd_slot=-1, keep=None, device=False,
+                 rgba_out=None, no_planes=False):
+    """Fill a Picture from numpy arrays (host) or raw device addresses (device=True: ints).
+    rgba_out: device address of the RGBA frame for the fused display conversion (always a device address)."""
     p = Picture()
     p.type, p.out_slot, p.ref_fwd_slot, p.ref_bwd_slot = ptype, out_slot, ref_fwd_slot, ref_bwd_slot
+    p.rgba_out = None if rgba_out is None else int(rgba_out)
+    p.no_planes = 1 if no_planes else 0
     if device:
         vals = (coef_y, coef_cb, coef_cr, qscale, intra, repadd, mv_fwd, mv_bwd, mb_dir)
         (p.coef_y, p.coef_cb, p.coef_cr, p.qscale, p.intra, p.repadd, p.mv_fwd, p.mv_bwd, p.mb_dir) = \
@@ -151,10 +158,13 @@ def make_picture(ptype, out_slot, coef_y, coef_cb, coef_cr, qscale, intra, repad
 
 
 def make_sparse_picture(ptype, out_slot, grp_off, entries, n_entries, qscale, intra, repadd=None, mv_fwd=None,
-                        mv_bwd=None, mb_dir=None, ref_fwd_slot=-1, ref_bwd_slot=-1, keep=None, device=False):
+                        mv_bwd=None, mb_dir=None, ref_fwd_slot=-1, ref_bwd_slot=-1, keep=None, device=False,
+                        rgba_out=None, no_planes=False):
     """The sparse-boundary twin of make_picture (lists in the format of include/leon_vlc.h)."""
     p = SparsePicture()
     p.type, p.out_slot, p.ref_fwd_slot, p.ref_bwd_slot = ptype, out_slot, ref_fwd_slot, ref_bwd_slot
+    p.rgba_out = None if rgba_out is None else int(rgba_out)
+    p.no_planes = 1 if no_planes else 0
     p.n_entries = int(n_entries)
     if device:
         vals = (grp_off, entries, qscale, intra, repadd, mv_fwd, mv_bwd, mb_dir)

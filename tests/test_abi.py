@@ -21,13 +21,13 @@ def test_header_symbols_all_exported():
     for n in names:
         assert hasattr(lib, n), "libleon_hip.so does not export %s" % n
     assert set(names) == set(L.SYMBOLS)
-    assert lib.leon_abi_version() == 1
+    assert lib.leon_abi_version() == 2
 
 
 def test_struct_layouts():
     import leon_ctypes as L
     assert C.sizeof(L.Config) == 32 and L.Config.stream.offset == 24
-    assert C.sizeof(L.Picture) == 16 + 9 * 8 and L.Picture.coef_y.offset == 16
+    assert C.sizeof(L.Picture) == 16 + 9 * 8 + 16 and L.Picture.coef_y.offset == 16 and L.Picture.rgba_out.offset == 88
     assert C.sizeof(L.KernelStats) == 32
 
 

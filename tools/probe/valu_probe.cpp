@@ -64,6 +64,23 @@ typedef float v2f __attribute__((ext_vector_type(2)));
 #define OP_PKMUL(k) asm volatile("v_pk_mul_f32 %0, %0, %1" : "+v"(r[k]) : "v"(c));
 #define OP_MOVDPP(k) asm volatile("v_mov_b32_dpp %0, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r[k]) : "v"(c));
 #define OP_ADDDPP(k) asm volatile("v_add_u32_dpp %0, %1, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf" : "+v"(r[k]) : "v"(c));
+typedef double dbl;
+#define DECL_D double r[16]; for (int k = 0; k < 16; k++) r[k] = (double)(seed + k + threadIdx.x); double c = (double)seed * 1.0001
+#define SINK_D double s = 0; for (int k = 0; k < 16; k++) s += r[k]; if (s == 12345.0) out[0] = (int)s
+#define OP_ADDD(k) asm volatile("v_add_f64 %0, %0, %1" : "+v"(r[k]) : "v"(c));
+#define OP_MULD(k) asm volatile("v_mul_f64 %0, %0, %1" : "+v"(r[k]) : "v"(c));
+#define OP_FMAD(k) asm volatile("v_fma_f64 %0, %0, %1, %1" : "+v"(r[k]) : "v"(c));
+#define OP_CVTDU(k) { unsigned u_ = (unsigned)k + threadIdx.x; asm volatile("v_cvt_f64_u32 %0, %1" : "=v"(r[k]) : "v"(u_)); }
+#define OP_CVTID(k) { int i_; asm volatile("v_cvt_i32_f64 %0, %1" : "=v"(i_) : "v"(r[k])); asm volatile("" :: "v"(i_)); }
+#define OP_BPERM(k) asm volatile("ds_bpermute_b32 %0, %1, %0\n s_waitcnt lgkmcnt(0)" : "+v"(r[k]) : "v"(c));
+#define OP_MOV(k) asm volatile("v_mov_b32 %0, %1" : "=v"(r[k]) : "v"(c));
+KERNEL(k_addd, DECL_D, OP_ADDD, SINK_D)
+KERNEL(k_muld, DECL_D, OP_MULD, SINK_D)
+KERNEL(k_fmad, DECL_D, OP_FMAD, SINK_D)
+KERNEL(k_cvtdu, DECL_D, OP_CVTDU, SINK_D)
+KERNEL(k_cvtid, DECL_D, OP_CVTID, SINK_D)
+KERNEL(k_bperm, DECL_I, OP_BPERM, SINK_I)
+KERNEL(k_mov, DECL_I, OP_MOV, SINK_I)
 KERNEL(k_mul24, DECL_I, OP_MUL24, SINK_I)
 KERNEL(k_mulu24, DECL_I, OP_MULU24, SINK_I)
 KERNEL(k_mulhi, DECL_I, OP_MULHI, SINK_I)
@@ -125,13 +142,14 @@ int main()
         double waves_per_simd = wgs_per_cu * 4 / 4.0;   // 4 waves per WG over 4 SIMDs
         double instr_per_simd = waves_per_simd * ITER * 16.0;
         double us = best * 1e3;
-        printf("%-12s %.2f ns/instr/SIMD  (x %.2f of v_add_u32)\n", name, us * 1e3 / instr_per_simd, us * 1e3 / instr_per_simd / 1.10);
+        printf("%-12s %.2f ns/instr/SIMD  = %.2f wave64 instr per CU per clock at %.0f MHz\n", name, us * 1e3 / instr_per_simd, 4.0 / (us * 1e3 / instr_per_simd * mhz * 1e-3), mhz);
     };
 #define RUN(K) run(#K, K, 8);
     RUN(k_add) RUN(k_mad24) RUN(k_lshladd) RUN(k_ashr) RUN(k_med3) RUN(k_perm) RUN(k_lerp) RUN(k_mullo) RUN(k_pkaddi16) RUN(k_ashrpk)
     RUN(k_addf) RUN(k_fmaf) RUN(k_cvt) RUN(k_floor) RUN(k_pkadd) RUN(k_pkfma)
     RUN(k_mul24) RUN(k_mulu24) RUN(k_mulhi) RUN(k_cndmask) RUN(k_alignbyte) RUN(k_bfe) RUN(k_andor) RUN(k_add3) RUN(k_lshlor) RUN(k_max)
     RUN(k_and) RUN(k_xor) RUN(k_lshl) RUN(k_bitop3) RUN(k_satpk) RUN(k_addsdwa) RUN(k_mulsdwa) RUN(k_cmp) RUN(k_movdpp) RUN(k_adddpp)
+    RUN(k_addd) RUN(k_muld) RUN(k_fmad) RUN(k_cvtdu) RUN(k_cvtid) RUN(k_bperm) RUN(k_mov)
     RUN(k_cvtflr) RUN(k_cvti) RUN(k_mulf) RUN(k_fmac) RUN(k_max3f) RUN(k_trunc) RUN(k_cvtub) RUN(k_cvtpku8) RUN(k_pkmul)
     return 0;
 }
