@@ -91,7 +91,7 @@ typedef struct leon_picture {
      * picture (= renderFrameGL / YCbCrToRGBA, player/easybits.player.js:2787-2858 / :2674-2785, the
      * LEON_RGB_CPU_TWIN arithmetic) instead of a later leon_convert_rgba reading the planes back.
      * Needs frame_width % 8 == 0.  no_planes != 0: the slot's planes are not written at all -- for a
-     * picture nobody predicts from (B pictures); out_slot must still be a valid slot and stays untouched. */
+     * picture nobody predicts from (B pictures); out_slot is then ignored (-1 is accepted). */
     void*   rgba_out;
     int32_t no_planes;
     int32_t reserved;

@@ -1,0 +1,87 @@
+/*
+ * leon_pipeline.h -- native decode pipeline over libleon_vlc + libleon_hip (exported by libleon_hip.so).
+ *
+ * What it replaces in the reference: the page's decode loop -- decodeFrame() pulling one picture at
+ * a time through the bit-serial parser and one IDCT_GL per picture, on the page's only thread
+ * (decoders/jsv.js:426-469, :1593-1599, :1177-1336; player/easybits.player.js:2310-2324, :2543-2617).
+ * Here the same stream bytes go through
+ *     K parser threads   one libleon_vlc stream per GOP shard (cut at the key map, decoders/jsv.js:264-350;
+ *                        closed GOPs share nothing), lists and maps written straight into pinned memory
+ *     one submit thread  a window of W consecutive GOPs at a time: one asynchronous upload per GOP, then ONE
+ *                        kernel launch per picture type and dependency level ACROSS the window's GOPs, the
+ *                        display conversion fused in (leon_picture.rgba_out); B pictures write no planes
+ *     one notify thread  waits on the window's HIP event and calls back with the frames (RGBA8 in device
+ *                        memory, display order) -- no caller thread ever blocks on the GPU
+ * No interpreter is in the loop; a Node host learns of frames through a napi_threadsafe_function
+ * (mpeg1video-decoder-webgl_amd/napi/leon_napi.cc), the MI355X-side of the reference's 'frame' event
+ * (decoders/jsv.js:673).
+ *
+ * Requirements on the stream: JSV with a key map (or a raw elementary stream: one shard), closed GOPs,
+ * frame_width % 8 == 0 (fused display conversion).
+ */
+#ifndef LEON_PIPELINE_H
+#define LEON_PIPELINE_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct leon_pipeline leon_pipeline;
+
+typedef struct leon_pipeline_config {
+    int32_t device_id;
+    int32_t parser_threads;     /* K; <= 0: one per hardware thread, at most 16 */
+    int32_t gops_per_window;    /* W: independent GOPs decoded together = pictures per launch and type; <= 0: 32 */
+    int32_t windows_in_flight;  /* RGBA / staging rings; <= 0: 2 */
+    int32_t max_gop_pictures;   /* frames reserved per GOP in a window; <= 0: 16 */
+    int32_t loop;               /* benchmarking: decode the stream this many times over (GOP ids keep counting); <= 0: once */
+} leon_pipeline_config;
+
+/* One decoded picture.  rgba stays valid until leon_pipeline_release_window(window) */
+typedef struct leon_pipeline_frame {
+    uint64_t gop;               /* GOP id (key-map index, counting on across loops) */
+    int32_t  display_index;     /* temporal reference inside its GOP */
+    int32_t  type;              /* LEON_PIC_I / _P / _B */
+    double   ts_ms;             /* presentation time: GOP time code + display_index / picture rate */
+    void*    rgba;              /* DEVICE pointer: frame_width * frame_height * 4 bytes */
+} leon_pipeline_frame;
+
+/* Called on the pipeline's notify thread once per window, frames in display order (GOP-major).
+ * n_frames == 0 with window < 0 signals the end of the stream ('ended', decoders/jsv.js:437);
+ * status != 0 an error (leon_pipeline_error() has the text). */
+typedef void (*leon_pipeline_callback)(void* user, int64_t window, const leon_pipeline_frame* frames, int32_t n_frames, int32_t status);
+
+typedef struct leon_pipeline_info {
+    int32_t coded_width, coded_height, frame_width, frame_height;
+    double  picture_rate, duration;
+    uint32_t gops;              /* key-map entries (1 for a stream without key map) */
+    int32_t parser_threads, gops_per_window;
+} leon_pipeline_info;
+
+typedef struct leon_pipeline_stats {
+    uint64_t pictures, gops, windows, stream_bytes;
+    double   seconds;           /* first parser start -> last window completed (so far) */
+    double   parse_seconds_sum; /* summed over the parser threads */
+    double   upload_bytes;      /* what crossed PCIe */
+    uint64_t entries;           /* non-zero coefficients decoded */
+} leon_pipeline_stats;
+
+/* Copies nothing: `stream` must stay valid until leon_pipeline_destroy.  Starts decoding at once. */
+int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream, size_t bytes,
+                         leon_pipeline_callback cb, void* user, leon_pipeline** out);
+int leon_pipeline_get_info(leon_pipeline* p, leon_pipeline_info* out);
+/* the consumer is done with a window's frames: its RGBA ring entry and staging may be reused */
+int leon_pipeline_release_window(leon_pipeline* p, int64_t window);
+/* blocks until every window has been delivered (and released windows drained); returns the first error */
+int leon_pipeline_wait(leon_pipeline* p);
+int leon_pipeline_get_stats(leon_pipeline* p, leon_pipeline_stats* out);
+/* copy one frame of a delivered, not yet released window to host memory (tests, thumbnails) */
+int leon_pipeline_read_frame(leon_pipeline* p, const leon_pipeline_frame* f, uint8_t* rgba_host);
+const char* leon_pipeline_error(leon_pipeline* p);
+void leon_pipeline_destroy(leon_pipeline* p);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -82,7 +82,8 @@ typedef struct leon_vlc_picture {
 const char* leon_vlc_last_error(void);
 
 /* Copies `n` bytes of a JSV stream (container header + key map, decoders/jsv.js:237-313) or of a
- * raw MPEG-1 video elementary stream (starts with 00 00 01 B3).  threads <= 0: one per hardware
+ * raw MPEG-1 video elementary stream (starts with 00 00 01 B3), or of a GOP shard of a JSV stream
+ * (starts with its sequence header 00 00 01 C3, see leon_vlc_get_keymap).  threads <= 0: one per hardware
  * thread, at most 16.  Reads up to the first sequence header so that leon_vlc_get_info is valid. */
 int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_stream** out);
 void leon_vlc_close(leon_vlc_stream* s);
@@ -98,6 +99,13 @@ int leon_vlc_next_picture(leon_vlc_stream* s, leon_vlc_picture* out);
 /* = jsv.prototype.seek (decoders/jsv.js:1618-1648): position on the key-map entry at or before
  * `seconds`; decoding resumes at the next sequence header.  *byte_offset receives the offset. */
 int leon_vlc_seek(leon_vlc_stream* s, double seconds, uint64_t* byte_offset);
+
+/* The GOP key map of the container header (decoders/jsv.js:264-268, :282-313): absolute byte offset
+ * of each GOP's sequence header and its time code.  Fills at most `capacity` entries (either array
+ * may be NULL) and returns the number of entries the stream has.  A stream opened on the bytes from
+ * one entry's offset up to the next one's (a "GOP shard": it starts with 00 00 01 C3) decodes
+ * exactly that GOP -- the unit of the frame-parallel partition. */
+int leon_vlc_get_keymap(leon_vlc_stream* s, uint32_t* byte_offsets, uint32_t* timecodes, uint32_t capacity);
 
 /* sparse lists -> the dense int16 planes the reference uploads (planes are overwritten) */
 int leon_vlc_densify(const leon_vlc_info* info, const leon_vlc_picture* pic, int16_t* y, int16_t* cb, int16_t* cr);

@@ -237,7 +237,9 @@ int check_pic(const leon_decoder* d, const AnyPic& a)
 {
     const leon_picture& p = a.p;
     if (p.type < LEON_PIC_I || p.type > LEON_PIC_B) return fail(LEON_ERR_INVALID, "picture type %d", p.type);
-    if (p.out_slot < 0 || p.out_slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "out_slot %d", p.out_slot);
+    const bool writes_planes = !(p.rgba_out && p.no_planes);
+    if (writes_planes ? (p.out_slot < 0 || p.out_slot >= d->cfg.n_slots) : (p.out_slot < -1 || p.out_slot >= d->cfg.n_slots))
+        return fail(LEON_ERR_INVALID, "out_slot %d", p.out_slot);
     if (a.sparse) {
         if (!a.grp_off || (!a.entries && a.n_entries) || !p.qscale || !p.intra) return fail(LEON_ERR_INVALID, "null boundary tensor");
         if (a.n_entries > (uint32_t)d->geom.cw * (uint32_t)d->geom.ch * 3u / 2u)
@@ -246,12 +248,12 @@ int check_pic(const leon_decoder* d, const AnyPic& a)
     if (p.type != LEON_PIC_I) {
         if (p.ref_fwd_slot < 0 || p.ref_fwd_slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "ref_fwd_slot %d", p.ref_fwd_slot);
         if (!p.repadd || !p.mv_fwd) return fail(LEON_ERR_INVALID, "P/B picture without repadd/mv_fwd");
-        if (p.ref_fwd_slot == p.out_slot) return fail(LEON_ERR_INVALID, "out_slot equals ref_fwd_slot");
+        if (writes_planes && p.ref_fwd_slot == p.out_slot) return fail(LEON_ERR_INVALID, "out_slot equals ref_fwd_slot");
     }
     if (p.type == LEON_PIC_B) {
         if (p.ref_bwd_slot < 0 || p.ref_bwd_slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "ref_bwd_slot %d", p.ref_bwd_slot);
         if (!p.mv_bwd || !p.mb_dir) return fail(LEON_ERR_INVALID, "B picture without mv_bwd/mb_dir");
-        if (p.ref_bwd_slot == p.out_slot) return fail(LEON_ERR_INVALID, "out_slot equals ref_bwd_slot");
+        if (writes_planes && p.ref_bwd_slot == p.out_slot) return fail(LEON_ERR_INVALID, "out_slot equals ref_bwd_slot");
     }
     if (p.rgba_out) {
         if (d->cfg.frame_width & 7) return fail(LEON_ERR_INVALID, "fused display conversion needs frame_width %% 8 == 0 (it is %d)", d->cfg.frame_width);
@@ -275,7 +277,7 @@ void fill_desc(const leon_decoder* d, const AnyPic& a, PicDesc& o)
     o.mb_dir = p.mb_dir;
     o.mv_fwd = p.mv_fwd;
     o.mv_bwd = p.mv_bwd;
-    o.out = d->d_slots + (size_t)p.out_slot * d->slot_stride;
+    o.out = d->d_slots + (size_t)(p.out_slot < 0 ? 0 : p.out_slot) * d->slot_stride;   // not written when no_planes
     o.ref_fwd = p.type != LEON_PIC_I ? d->d_slots + (size_t)p.ref_fwd_slot * d->slot_stride : nullptr;
     o.ref_bwd = p.type == LEON_PIC_B ? d->d_slots + (size_t)p.ref_bwd_slot * d->slot_stride : nullptr;
     o.type = p.type;
@@ -289,7 +291,7 @@ int guard_pending_conversions(leon_decoder* d, const int32_t* out_slots, int n)
 {
     if (!d->overlap_convert || d->conv_pending.empty()) return LEON_OK;
     bool hit = false;
-    for (int i = 0; i < n && !hit; i++) hit = d->conv_pending[out_slots[i]] != 0;
+    for (int i = 0; i < n && !hit; i++) hit = out_slots[i] >= 0 && d->conv_pending[out_slots[i]] != 0;
     if (hit) {
         HIP_TRY(hipStreamWaitEvent(d->stream, d->ev_conv_done, 0));
         std::fill(d->conv_pending.begin(), d->conv_pending.end(), 0);
@@ -663,6 +665,7 @@ int check_batch(leon_decoder* d, const AnyPic* pics, int n)
         d->epoch = 1;
     }
     for (int i = 0; i < n; i++) {
+        if (pics[i].p.rgba_out && pics[i].p.no_planes) continue;       // writes no slot
         const int s = pics[i].p.out_slot;
         if (d->writer_epoch[s] == d->epoch)
             return fail(LEON_ERR_INVALID, "pictures %d and %d of one batch depend on each other (both write slot %d)", d->writer_of[s], i, s);
@@ -1056,3 +1059,7 @@ int leon_measure_copy_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, do
 }
 
 }  // extern "C"
+
+// the native decode pipeline (include/leon_pipeline.h) lives in the same translation unit: it drives
+// the decoder through the internals above
+#include "leon_pipeline_impl.h"

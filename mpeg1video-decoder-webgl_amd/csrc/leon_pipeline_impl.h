@@ -1,0 +1,622 @@
+// leon_pipeline_impl.h -- implementation of include/leon_pipeline.h; included at the end of leon_hip.cpp
+// (it uses the decoder's internals: submit_batch_any, the slot ring, the decoder's stream).
+#include "../../include/leon_pipeline.h"
+#include "../../include/leon_vlc.h"
+
+#include <atomic>
+#include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <map>
+#include <mutex>
+#include <thread>
+
+namespace {
+
+using Clock = std::chrono::steady_clock;
+
+struct PipePic {                 // one parsed picture: offsets of its arrays inside the GOP's arena
+    int32_t type, tref;
+    uint32_t n_entries;
+    double ts_ms;
+    size_t grp_off, entries, qscale, intra, repadd, mb_dir, mv_fwd, mv_bwd;   // (size_t)-1: absent
+};
+
+struct Arena {                   // pinned host buffer + its device twin, one GOP at a time
+    char* host = nullptr;
+    char* dev = nullptr;
+    size_t cap = 0, used = 0;
+};
+
+struct GopJob {
+    uint64_t gop = 0;
+    Arena* arena = nullptr;
+    std::vector<PipePic> pics;
+    double gop_ts_ms = 0;
+    int status = LEON_OK;
+    std::string err;
+};
+
+struct PipeWindow {
+    int64_t id = 0;
+    int ring = 0;
+    std::vector<GopJob*> jobs;
+    std::vector<leon_pipeline_frame> frames;
+    hipEvent_t done = nullptr;
+    int status = LEON_OK;
+};
+
+constexpr size_t kNone = (size_t)-1;
+inline size_t pad256(size_t v) { return (v + 255) / 256 * 256; }
+
+}  // namespace
+
+struct leon_pipeline {
+    leon_pipeline_config cfg{};
+    leon_pipeline_info info{};
+    const uint8_t* stream = nullptr;
+    size_t bytes = 0;
+    leon_pipeline_callback cb = nullptr;
+    void* user = nullptr;
+    leon_vlc_info vinfo{};
+    std::vector<uint64_t> shard_begin, shard_end;     // byte ranges of the GOP shards
+    uint64_t total_gops = 0;                          // gops * loop
+    int W = 32, R = 2, K = 1, max_pics = 16;
+    size_t frame_bytes = 0;
+
+    leon_decoder* dec = nullptr;
+    hipStream_t copy_stream = nullptr;
+    uint8_t* d_rgba = nullptr;                        // R ring entries of W * max_pics frames
+
+    std::mutex mu;
+    std::condition_variable cv;
+    std::atomic<uint64_t> next_gop{0};
+    std::map<uint64_t, GopJob*> parsed;               // waiting for the submit thread
+    std::deque<Arena*> free_arenas;
+    std::deque<PipeWindow*> to_notify;
+    std::vector<int64_t> ring_owner;                  // window id holding a ring entry, -1 free
+    std::map<int64_t, PipeWindow*> delivered;         // waiting for release
+    int64_t windows_submitted = 0, windows_done = 0, total_windows = 0;
+    bool stop = false, finished = false, quiet = false, submit_exited = false;
+    int status = LEON_OK;
+    std::string err;
+
+    std::vector<std::thread> parsers;
+    std::thread submitter, notifier;
+    std::vector<Arena*> all_arenas;
+
+    // stats
+    Clock::time_point t0;
+    std::atomic<uint64_t> st_pictures{0}, st_gops{0}, st_entries{0}, st_parse_ns{0}, st_upload{0};
+    double st_seconds = 0;
+};
+
+namespace {
+
+void pipe_fail(leon_pipeline* p, int code, const std::string& msg)
+{
+    std::lock_guard<std::mutex> lk(p->mu);
+    if (p->status == LEON_OK) {
+        p->status = code;
+        p->err = msg;
+    }
+    p->stop = true;
+    p->cv.notify_all();
+}
+
+bool arena_reserve(leon_pipeline* p, Arena* a, size_t need)
+{
+    if (need <= a->cap) return true;
+    size_t cap = std::max(need + need / 2, (size_t)8 << 20);
+    char *h = nullptr, *dv = nullptr;
+    if (hipHostMalloc((void**)&h, cap, hipHostMallocDefault) != hipSuccess) return false;
+    if (hipMalloc((void**)&dv, cap) != hipSuccess) {
+        hipHostFree(h);
+        return false;
+    }
+    if (a->used) memcpy(h, a->host, a->used);
+    if (a->host) hipHostFree(a->host);
+    if (a->dev) hipFree(a->dev);        // only ever grown while the arena is being filled: nothing in flight reads it
+    a->host = h;
+    a->dev = dv;
+    a->cap = cap;
+    return true;
+}
+
+// one GOP shard: parse every picture of it straight into a pinned arena
+void parse_gop(leon_pipeline* p, GopJob* job)
+{
+    const uint64_t g = job->gop % p->shard_begin.size();
+    const uint8_t* b = p->stream + p->shard_begin[g];
+    const size_t n = (size_t)(p->shard_end[g] - p->shard_begin[g]);
+    leon_vlc_stream* st = nullptr;
+    // a stream without key map is one shard that still carries its container header
+    if (leon_vlc_open(b, n, 1, &st) != LEON_VLC_OK) {
+        job->status = LEON_ERR_INVALID;
+        job->err = std::string("GOP shard ") + std::to_string(g) + ": " + leon_vlc_last_error();
+        return;
+    }
+    const size_t mbs = (size_t)p->vinfo.mb_width * p->vinfo.mb_height;
+    const size_t mpad = pad256(mbs), vpad = pad256(mbs * 4), gpad = pad256(((size_t)p->vinfo.n_groups + 1) * 4);
+    Arena* a = job->arena;
+    a->used = 0;
+    leon_vlc_picture pic;
+    for (;;) {
+        const int rc = leon_vlc_next_picture(st, &pic);
+        if (rc == LEON_VLC_END) break;
+        if (rc != LEON_VLC_PICTURE) {
+            job->status = LEON_ERR_INVALID;
+            job->err = std::string("GOP shard ") + std::to_string(g) + ": " + leon_vlc_last_error();
+            break;
+        }
+        const size_t epad = pad256((size_t)pic.n_entries * 4 + 4);
+        const size_t need = a->used + gpad + epad + 4 * mpad + 2 * vpad;
+        if (!arena_reserve(p, a, need)) {
+            job->status = LEON_ERR_NOMEM;
+            job->err = "pinned staging allocation failed";
+            break;
+        }
+        PipePic m{};
+        m.type = pic.type;
+        m.tref = pic.temporal_reference;
+        m.n_entries = pic.n_entries;
+        m.ts_ms = pic.ts_ms;
+        auto put = [&](const void* src, size_t nbytes, size_t reserve) -> size_t {
+            if (!src) return kNone;
+            const size_t at = a->used;
+            memcpy(a->host + at, src, nbytes);
+            a->used += reserve;
+            return at;
+        };
+        m.grp_off = put(pic.grp_off, ((size_t)pic.n_groups + 1) * 4, gpad);
+        m.entries = put(pic.entries ? (const void*)pic.entries : (const void*)pic.grp_off, (size_t)pic.n_entries * 4, epad);
+        m.qscale = put(pic.qscale, mbs, mpad);
+        m.intra = put(pic.intra, mbs, mpad);
+        m.repadd = put(pic.type != LEON_PIC_I ? pic.repadd : nullptr, mbs, mpad);
+        m.mb_dir = put(pic.type == LEON_PIC_B ? pic.mb_dir : nullptr, mbs, mpad);
+        m.mv_fwd = put(pic.type != LEON_PIC_I ? pic.mv_fwd : nullptr, mbs * 4, vpad);
+        m.mv_bwd = put(pic.type == LEON_PIC_B ? pic.mv_bwd : nullptr, mbs * 4, vpad);
+        if (job->pics.empty()) job->gop_ts_ms = pic.ts_ms;
+        job->pics.push_back(m);
+        p->st_entries += pic.n_entries;
+    }
+    leon_vlc_close(st);
+    if (job->status == LEON_OK && (int)job->pics.size() > p->max_pics) {
+        job->status = LEON_ERR_INVALID;
+        job->err = "a GOP has " + std::to_string(job->pics.size()) + " pictures; raise max_gop_pictures (" + std::to_string(p->max_pics) + ")";
+    }
+}
+
+void parser_main(leon_pipeline* p)
+{
+    hipSetDevice(p->cfg.device_id);
+    for (;;) {
+        Arena* a = nullptr;
+        uint64_t g;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            // an arena is the ticket to parse ahead: there are W * (R + 1) of them
+            p->cv.wait(lk, [&] { return p->stop || !p->free_arenas.empty(); });
+            if (p->stop) return;
+            g = p->next_gop.load();
+            if (g >= p->total_gops) return;
+            p->next_gop = g + 1;
+            a = p->free_arenas.front();
+            p->free_arenas.pop_front();
+        }
+        GopJob* job = new GopJob();
+        job->gop = g;
+        job->arena = a;
+        const auto t = Clock::now();
+        parse_gop(p, job);
+        p->st_parse_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t).count();
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->parsed[g] = job;
+        }
+        p->cv.notify_all();
+    }
+}
+
+// the pictures of one window as launches: per GOP the anchors rotate through three slots; a picture's
+// level is one more than the deepest picture it predicts from, and a level is one batch
+int submit_window(leon_pipeline* p, PipeWindow* w)
+{
+    leon_decoder* d = p->dec;
+    const size_t lanes = w->jobs.size();
+    struct Item { size_t lane; const PipePic* pic; int fwd, bwd, out; };
+    std::vector<std::vector<Item>> levels;
+    uint8_t* ring = p->d_rgba + (size_t)w->ring * p->W * p->max_pics * p->frame_bytes;
+    w->frames.clear();
+    for (size_t j = 0; j < lanes; j++) {
+        GopJob* job = w->jobs[j];
+        // upload the GOP's arena; everything of this window is copied before its first launch
+        if (job->arena->used) {
+            HIP_TRY(hipMemcpyAsync(job->arena->dev, job->arena->host, job->arena->used, hipMemcpyHostToDevice, p->copy_stream));
+            p->st_upload += job->arena->used;
+        }
+        int older = -1, newer = -1, lv_older = -1, lv_newer = -1, n_anchor = 0;      // anchor slots (0..2 of the lane) and their levels
+        for (const PipePic& m : job->pics) {
+            Item it{j, &m, -1, -1, -1};
+            int lv = 0;
+            if (m.type == LEON_PIC_I) {
+                it.out = (int)(3 * j) + n_anchor % 3;
+            } else if (m.type == LEON_PIC_P) {
+                if (newer < 0) return fail(LEON_ERR_INVALID, "GOP %llu: a P picture without a preceding anchor", (unsigned long long)job->gop);
+                it.fwd = newer;
+                lv = lv_newer + 1;
+                it.out = (int)(3 * j) + n_anchor % 3;
+            } else {
+                if (newer < 0) return fail(LEON_ERR_INVALID, "GOP %llu: a B picture without an anchor (open GOPs cannot be sharded)", (unsigned long long)job->gop);
+                // the leading B pictures of a closed GOP predict backward only (both references = the I picture)
+                it.bwd = newer;
+                it.fwd = older >= 0 ? older : newer;
+                lv = std::max(lv_newer, lv_older) + 1;
+            }
+            if (m.type != LEON_PIC_B) {
+                older = newer; lv_older = lv_newer;
+                newer = it.out; lv_newer = lv;
+                n_anchor++;
+            }
+            if ((size_t)lv >= levels.size()) levels.resize((size_t)lv + 1);
+            levels[(size_t)lv].push_back(it);
+            if (m.tref < 0 || m.tref >= p->max_pics) return fail(LEON_ERR_INVALID, "temporal reference %d outside the GOP", m.tref);
+        }
+    }
+    hipEvent_t copied = get_event(d);
+    if (!copied) return LEON_ERR_HIP;
+    HIP_TRY(hipEventRecord(copied, p->copy_stream));
+    HIP_TRY(hipStreamWaitEvent(d->stream, copied, 0));
+    d->ev_pool.push_back(copied);
+    std::vector<leon_sparse_picture> batch;
+    for (auto& lvl : levels) {
+        batch.clear();
+        for (const Item& it : lvl) {
+            const char* base = w->jobs[it.lane]->arena->dev;
+            const PipePic& m = *it.pic;
+            auto ptr = [&](size_t off) -> const void* { return off == kNone ? nullptr : (const void*)(base + off); };
+            leon_sparse_picture sp{};
+            sp.type = m.type;
+            sp.out_slot = it.out;
+            sp.ref_fwd_slot = it.fwd;
+            sp.ref_bwd_slot = it.bwd;
+            sp.grp_off = (const uint32_t*)ptr(m.grp_off);
+            sp.entries = (const uint32_t*)ptr(m.entries);
+            sp.n_entries = m.n_entries;
+            sp.qscale = (const uint8_t*)ptr(m.qscale);
+            sp.intra = (const uint8_t*)ptr(m.intra);
+            sp.repadd = (const uint8_t*)ptr(m.repadd);
+            sp.mb_dir = (const uint8_t*)ptr(m.mb_dir);
+            sp.mv_fwd = (const int16_t*)ptr(m.mv_fwd);
+            sp.mv_bwd = (const int16_t*)ptr(m.mv_bwd);
+            sp.rgba_out = ring + ((size_t)it.lane * p->max_pics + (size_t)m.tref) * p->frame_bytes;
+            sp.no_planes = m.type == LEON_PIC_B;
+            batch.push_back(sp);
+        }
+        if (batch.empty()) continue;
+        int rc = submit_batch_any(d, wrap(batch.data(), (int)batch.size()).data(), (int)batch.size(), LEON_MEM_DEVICE);
+        if (rc != LEON_OK) return rc;
+    }
+    HIP_TRY(hipEventRecord(w->done, d->stream));
+    // frames in display order, GOP-major
+    const double rate = p->vinfo.picture_rate > 0 ? p->vinfo.picture_rate : 25.0;
+    for (size_t j = 0; j < lanes; j++) {
+        GopJob* job = w->jobs[j];
+        // by temporal reference: a GOP cut short by the encoder may skip display positions
+        std::vector<const PipePic*> by_disp((size_t)p->max_pics, nullptr);
+        for (const PipePic& m : job->pics) by_disp[(size_t)m.tref] = &m;
+        for (size_t k = 0; k < by_disp.size(); k++) {
+            if (!by_disp[k]) continue;
+            leon_pipeline_frame f{};
+            f.gop = job->gop;
+            f.display_index = (int32_t)k;
+            f.type = by_disp[k]->type;
+            f.ts_ms = job->gop_ts_ms + 1000.0 * (double)k / rate;
+            f.rgba = ring + ((size_t)j * p->max_pics + k) * p->frame_bytes;
+            w->frames.push_back(f);
+        }
+        p->st_pictures += job->pics.size();
+    }
+    p->st_gops += lanes;
+    return LEON_OK;
+}
+
+void submit_loop(leon_pipeline* p);
+void submit_main(leon_pipeline* p)
+{
+    hipSetDevice(p->cfg.device_id);
+    submit_loop(p);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->submit_exited = true;
+    }
+    p->cv.notify_all();
+}
+
+void submit_loop(leon_pipeline* p)
+{
+    for (int64_t wid = 0; wid < p->total_windows; wid++) {
+        PipeWindow* w = new PipeWindow();
+        w->id = wid;
+        const uint64_t g0 = (uint64_t)wid * p->W, g1 = std::min<uint64_t>(g0 + p->W, p->total_gops);
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            // a free entry of the RGBA ring, then every GOP of the window parsed
+            p->cv.wait(lk, [&] {
+                if (p->stop) return true;
+                for (int r = 0; r < p->R; r++)
+                    if (p->ring_owner[r] < 0) return true;
+                return false;
+            });
+            if (p->stop) { delete w; return; }
+            for (int r = 0; r < p->R; r++)
+                if (p->ring_owner[r] < 0) { w->ring = r; p->ring_owner[r] = wid; break; }
+            p->cv.wait(lk, [&] {
+                if (p->stop) return true;
+                for (uint64_t g = g0; g < g1; g++)
+                    if (!p->parsed.count(g)) return false;
+                return true;
+            });
+            if (p->stop) { delete w; return; }
+            for (uint64_t g = g0; g < g1; g++) {
+                w->jobs.push_back(p->parsed[g]);
+                p->parsed.erase(g);
+            }
+        }
+        int rc = LEON_OK;
+        std::string msg;
+        for (GopJob* j : w->jobs)
+            if (j->status != LEON_OK && rc == LEON_OK) { rc = j->status; msg = j->err; }
+        if (rc == LEON_OK) {
+            if (hipEventCreateWithFlags(&w->done, hipEventDisableTiming) != hipSuccess) { rc = LEON_ERR_HIP; msg = "hipEventCreate failed"; }
+            else {
+                rc = submit_window(p, w);
+                if (rc != LEON_OK) msg = g_err;
+            }
+        }
+        w->status = rc;
+        if (rc != LEON_OK) pipe_fail(p, rc, msg);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->to_notify.push_back(w);
+            p->windows_submitted++;
+        }
+        p->cv.notify_all();
+        if (rc != LEON_OK) return;
+    }
+}
+
+void release_window_locked(leon_pipeline* p, PipeWindow* w)
+{
+    for (GopJob* j : w->jobs) {
+        p->free_arenas.push_back(j->arena);
+        delete j;
+    }
+    p->ring_owner[w->ring] = -1;
+    if (w->done) hipEventDestroy(w->done);
+    delete w;
+}
+
+void notify_main(leon_pipeline* p)
+{
+    hipSetDevice(p->cfg.device_id);
+    for (;;) {
+        PipeWindow* w = nullptr;
+        {
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv.wait(lk, [&] { return !p->to_notify.empty() || p->windows_done == p->total_windows || p->submit_exited; });
+            if (p->to_notify.empty()) break;
+            w = p->to_notify.front();
+            p->to_notify.pop_front();
+        }
+        if (w->status == LEON_OK && hipEventSynchronize(w->done) != hipSuccess) {
+            w->status = LEON_ERR_HIP;
+            pipe_fail(p, LEON_ERR_HIP, std::string("window ") + std::to_string(w->id) + ": " + hipGetErrorString(hipGetLastError()));
+        }
+        const int64_t id = w->id;
+        const int st = w->status;
+        bool quiet;
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->delivered[id] = w;
+            p->st_seconds = std::chrono::duration<double>(Clock::now() - p->t0).count();
+            quiet = p->quiet;
+        }
+        // frames are handed over outside the lock: the callback may release the window at once
+        if (p->cb && !quiet) p->cb(p->user, id, st == LEON_OK ? w->frames.data() : nullptr, st == LEON_OK ? (int32_t)w->frames.size() : 0, st);
+        else leon_pipeline_release_window(p, id);
+        {
+            std::lock_guard<std::mutex> lk(p->mu);
+            p->windows_done++;
+        }
+        p->cv.notify_all();
+    }
+    bool quiet;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->finished = true;
+        quiet = p->quiet;
+    }
+    p->cv.notify_all();
+    if (p->cb && !quiet) p->cb(p->user, -1, nullptr, 0, p->status);     // 'ended' (or the error that stopped the run)
+}
+
+}  // namespace
+
+extern "C" {
+
+int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream, size_t bytes,
+                         leon_pipeline_callback cb, void* user, leon_pipeline** out)
+{
+    if (!cfg || !stream || bytes < 16 || !out) return fail(LEON_ERR_INVALID, "null argument");
+    *out = nullptr;
+    leon_vlc_stream* st = nullptr;
+    if (leon_vlc_open(stream, bytes, 1, &st) != LEON_VLC_OK) return fail(LEON_ERR_INVALID, "stream: %s", leon_vlc_last_error());
+    leon_pipeline* p = new (std::nothrow) leon_pipeline();
+    if (!p) { leon_vlc_close(st); return fail(LEON_ERR_NOMEM, "out of host memory"); }
+    leon_vlc_get_info(st, &p->vinfo);
+    const int n_keys = leon_vlc_get_keymap(st, nullptr, nullptr, 0);
+    std::vector<uint32_t> offs((size_t)std::max(n_keys, 0));
+    if (n_keys > 0) leon_vlc_get_keymap(st, offs.data(), nullptr, (uint32_t)n_keys);
+    leon_vlc_close(st);
+    p->cfg = *cfg;
+    p->stream = stream;
+    p->bytes = bytes;
+    p->cb = cb;
+    p->user = user;
+    if (n_keys > 0) {
+        for (int g = 0; g < n_keys; g++) {
+            const uint64_t b = offs[(size_t)g], e = g + 1 < n_keys ? offs[(size_t)g + 1] : bytes;
+            if (b >= e || e > bytes || b + 4 > bytes || stream[b] != 0 || stream[b + 1] != 0 || stream[b + 2] != 1) {
+                delete p;
+                return fail(LEON_ERR_INVALID, "key map entry %d does not point at a start code", g);
+            }
+            p->shard_begin.push_back(b);
+            p->shard_end.push_back(e);
+        }
+    } else {            // no key map: the whole stream is one shard
+        p->shard_begin.push_back(0);
+        p->shard_end.push_back(bytes);
+    }
+    const int loops = cfg->loop > 0 ? cfg->loop : 1;
+    p->total_gops = (uint64_t)p->shard_begin.size() * (uint64_t)loops;
+    p->W = cfg->gops_per_window > 0 ? cfg->gops_per_window : 32;
+    if ((uint64_t)p->W > p->total_gops) p->W = (int)p->total_gops;
+    p->R = cfg->windows_in_flight > 0 ? cfg->windows_in_flight : 2;
+    p->max_pics = cfg->max_gop_pictures > 0 ? cfg->max_gop_pictures : 16;
+    int k = cfg->parser_threads;
+    if (k <= 0) { k = (int)std::thread::hardware_concurrency(); if (k < 1) k = 1; if (k > 16) k = 16; }
+    p->K = k;
+    p->total_windows = (int64_t)((p->total_gops + p->W - 1) / p->W);
+    p->frame_bytes = (size_t)p->vinfo.frame_width * p->vinfo.frame_height * 4;
+    p->info.coded_width = p->vinfo.coded_width; p->info.coded_height = p->vinfo.coded_height;
+    p->info.frame_width = p->vinfo.frame_width; p->info.frame_height = p->vinfo.frame_height;
+    p->info.picture_rate = p->vinfo.picture_rate; p->info.duration = p->vinfo.duration;
+    p->info.gops = (uint32_t)p->shard_begin.size();
+    p->info.parser_threads = p->K; p->info.gops_per_window = p->W;
+    if (p->vinfo.frame_width & 7) { delete p; return fail(LEON_ERR_INVALID, "the pipeline needs frame_width %% 8 == 0 (it is %d)", p->vinfo.frame_width); }
+
+    leon_config dc{};
+    dc.coded_width = p->vinfo.coded_width; dc.coded_height = p->vinfo.coded_height;
+    dc.frame_width = p->vinfo.frame_width; dc.frame_height = p->vinfo.frame_height;
+    dc.n_slots = 3 * p->W;
+    dc.device_id = cfg->device_id;
+    int rc = leon_create(&dc, &p->dec);
+    if (rc != LEON_OK) { delete p; return rc; }
+    rc = leon_set_quant_matrices(p->dec, p->vinfo.intra_qm, p->vinfo.non_intra_qm);
+    auto bail = [&](int code, const char* what) {
+        std::string m = std::string(what) + ": " + hipGetErrorString(hipGetLastError());
+        leon_pipeline_destroy(p);
+        return fail(code, "%s", m.c_str());
+    };
+    if (rc != LEON_OK) { leon_pipeline_destroy(p); return rc; }
+    if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(LEON_ERR_HIP, "copy stream");
+    if (hipMalloc((void**)&p->d_rgba, (size_t)p->R * p->W * p->max_pics * p->frame_bytes) != hipSuccess) return bail(LEON_ERR_NOMEM, "RGBA ring");
+    p->ring_owner.assign((size_t)p->R, -1);
+    const int n_arenas = p->W * (p->R + 1);
+    for (int i = 0; i < n_arenas; i++) {
+        Arena* a = new Arena();
+        p->all_arenas.push_back(a);
+        p->free_arenas.push_back(a);
+    }
+    p->t0 = Clock::now();
+    for (int i = 0; i < p->K; i++) p->parsers.emplace_back(parser_main, p);
+    p->submitter = std::thread(submit_main, p);
+    p->notifier = std::thread(notify_main, p);
+    *out = p;
+    return LEON_OK;
+}
+
+int leon_pipeline_get_info(leon_pipeline* p, leon_pipeline_info* out)
+{
+    if (!p || !out) return fail(LEON_ERR_INVALID, "null argument");
+    *out = p->info;
+    return LEON_OK;
+}
+
+int leon_pipeline_release_window(leon_pipeline* p, int64_t window)
+{
+    if (!p) return fail(LEON_ERR_INVALID, "null pipeline");
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        auto it = p->delivered.find(window);
+        if (it == p->delivered.end()) return fail(LEON_ERR_INVALID, "window %lld is not out for delivery", (long long)window);
+        release_window_locked(p, it->second);
+        p->delivered.erase(it);
+    }
+    p->cv.notify_all();
+    return LEON_OK;
+}
+
+int leon_pipeline_wait(leon_pipeline* p)
+{
+    if (!p) return fail(LEON_ERR_INVALID, "null pipeline");
+    std::unique_lock<std::mutex> lk(p->mu);
+    p->cv.wait(lk, [&] { return p->finished; });
+    if (p->status != LEON_OK) return fail(p->status, "%s", p->err.c_str());
+    return LEON_OK;
+}
+
+int leon_pipeline_get_stats(leon_pipeline* p, leon_pipeline_stats* out)
+{
+    if (!p || !out) return fail(LEON_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> lk(p->mu);
+    out->pictures = p->st_pictures;
+    out->gops = p->st_gops;
+    out->windows = (uint64_t)p->windows_done;
+    out->stream_bytes = p->bytes;
+    out->seconds = p->st_seconds;
+    out->parse_seconds_sum = (double)p->st_parse_ns.load() * 1e-9;
+    out->upload_bytes = (double)p->st_upload.load();
+    out->entries = p->st_entries;
+    return LEON_OK;
+}
+
+int leon_pipeline_read_frame(leon_pipeline* p, const leon_pipeline_frame* f, uint8_t* rgba_host)
+{
+    if (!p || !f || !f->rgba || !rgba_host) return fail(LEON_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(p->cfg.device_id));
+    HIP_TRY(hipMemcpy(rgba_host, f->rgba, p->frame_bytes, hipMemcpyDeviceToHost));
+    return LEON_OK;
+}
+
+const char* leon_pipeline_error(leon_pipeline* p)
+{
+    if (!p) return "";
+    std::lock_guard<std::mutex> lk(p->mu);
+    return p->err.c_str();
+}
+
+void leon_pipeline_destroy(leon_pipeline* p)
+{
+    if (!p) return;
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->stop = true;
+        p->quiet = true;           // no callbacks while tearing down
+    }
+    p->cv.notify_all();
+    for (auto& t : p->parsers) if (t.joinable()) t.join();
+    if (p->submitter.joinable()) p->submitter.join();
+    if (p->notifier.joinable()) p->notifier.join();      // drains what was submitted, releasing instead of delivering
+    hipSetDevice(p->cfg.device_id);
+    if (p->dec) leon_sync(p->dec);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        for (auto& kv : p->delivered) release_window_locked(p, kv.second);
+        p->delivered.clear();
+        for (auto& kv : p->parsed) delete kv.second;
+        p->parsed.clear();
+    }
+    for (Arena* a : p->all_arenas) {
+        if (a->host) hipHostFree(a->host);
+        if (a->dev) hipFree(a->dev);
+        delete a;
+    }
+    if (p->d_rgba) hipFree(p->d_rgba);
+    if (p->copy_stream) hipStreamDestroy(p->copy_stream);
+    if (p->dec) leon_destroy(p->dec);
+    delete p;
+}
+
+}  // extern "C"

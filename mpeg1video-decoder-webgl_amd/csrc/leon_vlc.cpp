@@ -760,7 +760,10 @@ int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_strea
     (void)tables();
     Bits& r = s->r;
     s->raw_es = data[0] == 0 && data[1] == 0 && data[2] == 1 && data[3] == START_SEQUENCE_ES;
-    if (!s->raw_es) {
+    // a GOP shard cut out of a JSV stream at a key-map entry starts with the JSV sequence header itself
+    const bool shard = data[0] == 0 && data[1] == 0 && data[2] == 1 && data[3] == START_SEQUENCE;
+    s->info.has_alpha = -1;
+    if (!s->raw_es && !shard) {
         // container header: decoders/jsv.js:237-313
         r.skip(16);
         r.get(16);
@@ -982,6 +985,17 @@ int leon_vlc_seek(leon_vlc_stream* s, double seconds, uint64_t* byte_offset)
     s->skip_till_gop = true;
     if (byte_offset) *byte_offset = offset;
     return LEON_VLC_OK;
+}
+
+int leon_vlc_get_keymap(leon_vlc_stream* s, uint32_t* byte_offsets, uint32_t* timecodes, uint32_t capacity)
+{
+    if (!s) return fail(LEON_VLC_ERR_INVALID, "null argument");
+    const uint32_t count = (uint32_t)(s->keymap.size() / 2);
+    for (uint32_t g = 0; g < count && g < capacity; g++) {
+        if (byte_offsets) byte_offsets[g] = s->keymap[2 * g];
+        if (timecodes) timecodes[g] = s->keymap[2 * g + 1];
+    }
+    return (int)count;
 }
 
 int leon_vlc_densify(const leon_vlc_info* I, const leon_vlc_picture* p, int16_t* y, int16_t* cb, int16_t* cr)

@@ -28,6 +28,11 @@ SYMBOLS = [
     "leon_slot_device_ptr", "leon_sync", "leon_set_overlap_convert", "leon_timing_enable", "leon_timing_reset", "leon_timing_get",
     "leon_measure_copy_bandwidth",
 ]
+# include/leon_pipeline.h (same library)
+PIPELINE_SYMBOLS = [
+    "leon_pipeline_create", "leon_pipeline_get_info", "leon_pipeline_release_window", "leon_pipeline_wait",
+    "leon_pipeline_get_stats", "leon_pipeline_read_frame", "leon_pipeline_error", "leon_pipeline_destroy",
+]
 
 
 class LeonError(RuntimeError):
@@ -64,6 +69,29 @@ class KernelStats(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double),
                 ("macroblocks", C.c_uint64)]
 
+
+class PipelineConfig(C.Structure):
+    _fields_ = [("device_id", C.c_int32), ("parser_threads", C.c_int32), ("gops_per_window", C.c_int32),
+                ("windows_in_flight", C.c_int32), ("max_gop_pictures", C.c_int32), ("loop", C.c_int32)]
+
+
+class PipelineFrame(C.Structure):
+    _fields_ = [("gop", C.c_uint64), ("display_index", C.c_int32), ("type", C.c_int32), ("ts_ms", C.c_double),
+                ("rgba", C.c_void_p)]
+
+
+class PipelineInfo(C.Structure):
+    _fields_ = [("coded_width", C.c_int32), ("coded_height", C.c_int32), ("frame_width", C.c_int32), ("frame_height", C.c_int32),
+                ("picture_rate", C.c_double), ("duration", C.c_double), ("gops", C.c_uint32), ("parser_threads", C.c_int32),
+                ("gops_per_window", C.c_int32)]
+
+
+class PipelineStats(C.Structure):
+    _fields_ = [("pictures", C.c_uint64), ("gops", C.c_uint64), ("windows", C.c_uint64), ("stream_bytes", C.c_uint64),
+                ("seconds", C.c_double), ("parse_seconds_sum", C.c_double), ("upload_bytes", C.c_double), ("entries", C.c_uint64)]
+
+
+PIPELINE_CB = C.CFUNCTYPE(None, C.c_void_p, C.c_int64, C.POINTER(PipelineFrame), C.c_int32, C.c_int32)
 
 _lib = None
 
@@ -112,6 +140,16 @@ def load():
     lib.leon_timing_reset.argtypes = [C.c_void_p]
     lib.leon_timing_get.argtypes = [C.c_void_p, C.c_int32, C.POINTER(KernelStats)]
     lib.leon_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double)]
+    lib.leon_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.c_void_p, C.c_size_t, PIPELINE_CB, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.leon_pipeline_get_info.argtypes = [C.c_void_p, C.POINTER(PipelineInfo)]
+    lib.leon_pipeline_release_window.argtypes = [C.c_void_p, C.c_int64]
+    lib.leon_pipeline_wait.argtypes = [C.c_void_p]
+    lib.leon_pipeline_get_stats.argtypes = [C.c_void_p, C.POINTER(PipelineStats)]
+    lib.leon_pipeline_read_frame.argtypes = [C.c_void_p, C.POINTER(PipelineFrame), C.c_void_p]
+    lib.leon_pipeline_error.argtypes = [C.c_void_p]
+    lib.leon_pipeline_error.restype = C.c_char_p
+    lib.leon_pipeline_destroy.argtypes = [C.c_void_p]
+    lib.leon_pipeline_destroy.restype = None
     _lib = lib
     return lib
 
@@ -301,3 +339,80 @@ class Decoder:
         g = C.c_double()
         _chk(self.lib.leon_measure_copy_bandwidth(self.h, nbytes, iters, C.byref(g)))
         return g.value
+
+
+class Pipeline:
+    """leon_pipeline_* (include/leon_pipeline.h): stream bytes in, RGBA frames in device memory out.
+    on_window(window_id, frames) runs on the pipeline's notify thread with a list of dicts
+    (gop, display_index, type, ts_ms, rgba = device address); unless it returns False the window is
+    released right after.  read_frame(frame) works until the frame's window is released."""
+
+    def __init__(self, data, device_id=0, parser_threads=0, gops_per_window=0, windows_in_flight=0, max_gop_pictures=0,
+                 loop=0, on_window=None):
+        self.lib = load()
+        self._data = (C.c_uint8 * len(data)).from_buffer_copy(data)      # must outlive the pipeline
+        self._on_window = on_window
+        self.windows = 0
+        self.frames = 0
+        self.ended = False
+        self.error = None
+
+        def _cb(_user, window, frames, n, status):
+            try:
+                if window < 0:
+                    self.ended = True
+                    return
+                if status != OK:
+                    self.error = status
+                    self.lib.leon_pipeline_release_window(self.h, window)
+                    return
+                self.windows += 1
+                self.frames += n
+                keep = None
+                if self._on_window is not None:
+                    fl = [{"gop": int(frames[i].gop), "display_index": frames[i].display_index, "type": frames[i].type,
+                           "ts_ms": frames[i].ts_ms, "rgba": frames[i].rgba, "_i": i, "_frames": frames} for i in range(n)]
+                    keep = self._on_window(window, fl)
+                if keep is not False:
+                    self.lib.leon_pipeline_release_window(self.h, window)
+            except Exception as e:      # never let an exception cross the C boundary
+                self.error = e
+        self._cb = PIPELINE_CB(_cb)
+        cfg = PipelineConfig(device_id, parser_threads, gops_per_window, windows_in_flight, max_gop_pictures, loop)
+        h = C.c_void_p()
+        self.h = None
+        rc = self.lib.leon_pipeline_create(C.byref(cfg), self._data, len(data), self._cb, None, C.byref(h))
+        _chk(rc)
+        self.h = h
+        info = PipelineInfo()
+        _chk(self.lib.leon_pipeline_get_info(self.h, C.byref(info)))
+        self.info = info
+
+    def read_frame(self, frame):
+        out = np.empty((self.info.frame_height, self.info.frame_width, 4), dtype=np.uint8)
+        _chk(self.lib.leon_pipeline_read_frame(self.h, C.byref(frame["_frames"][frame["_i"]]), out.ctypes.data))
+        return out
+
+    def release_window(self, window):
+        _chk(self.lib.leon_pipeline_release_window(self.h, window))
+
+    def wait(self):
+        _chk(self.lib.leon_pipeline_wait(self.h))
+        if isinstance(self.error, Exception):
+            raise self.error
+
+    def stats(self):
+        s = PipelineStats()
+        _chk(self.lib.leon_pipeline_get_stats(self.h, C.byref(s)))
+        return {n: getattr(s, n) for n, _ in PipelineStats._fields_}
+
+    def close(self):
+        if self.h:
+            self.lib.leon_pipeline_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

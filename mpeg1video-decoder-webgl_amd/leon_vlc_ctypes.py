@@ -8,7 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SYMBOLS = ["leon_vlc_last_error", "leon_vlc_open", "leon_vlc_close", "leon_vlc_get_info",
-           "leon_vlc_next_picture", "leon_vlc_seek", "leon_vlc_densify"]
+           "leon_vlc_next_picture", "leon_vlc_seek", "leon_vlc_densify", "leon_vlc_get_keymap"]
 
 
 class Info(C.Structure):
@@ -45,6 +45,7 @@ def load():
     lib.leon_vlc_close.restype = None
     lib.leon_vlc_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     lib.leon_vlc_next_picture.argtypes = [C.c_void_p, C.POINTER(Picture)]
+    lib.leon_vlc_get_keymap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.leon_vlc_seek.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_uint64)]
     lib.leon_vlc_densify.argtypes = [C.POINTER(Info), C.POINTER(Picture), C.c_void_p, C.c_void_p, C.c_void_p]
     _lib = lib
@@ -114,6 +115,13 @@ class Stream:
                 raise VlcError(self.lib.leon_vlc_last_error().decode())
             out["coef_y"], out["coef_cb"], out["coef_cr"] = y, cb, cr
         return out
+
+    def keymap(self):
+        """byte offsets of the GOP shards (leon_vlc_get_keymap)"""
+        n = self.lib.leon_vlc_get_keymap(self.h, None, None, 0)
+        offs = (C.c_uint32 * max(n, 1))()
+        self.lib.leon_vlc_get_keymap(self.h, offs, None, n)
+        return [int(offs[i]) for i in range(n)]
 
     def seek(self, seconds):
         off = C.c_uint64()

@@ -16,6 +16,10 @@
 #include <cstdio>
 #include <cstring>
 #include "../../include/leon.h"
+#include "../../include/leon_pipeline.h"
+#include <map>
+#include <mutex>
+#include <vector>
 
 namespace {
 
@@ -345,6 +349,237 @@ napi_value Create(napi_env env, napi_callback_info info)
     return obj;
 }
 
+// ---- the native pipeline (include/leon_pipeline.h) -----------------------------------------------------
+//   const p = leon.createPipeline(streamBuffer, {deviceId, parserThreads, gopsPerWindow, windowsInFlight,
+//                                                maxGopPictures, loop}, (window, frames, status) => {...});
+//   frames: [{gop, displayIndex, type, ts}] in display order; window < 0 = 'ended' (decoders/jsv.js:437).
+//   p.readFrame(window, i) -> Uint8Array (copies one frame to the host: tests, thumbnails),
+//   p.releaseWindow(window), p.stats(), p.info(), p.destroy().
+// The callback arrives on the JavaScript thread through a napi_threadsafe_function: the pipeline's notify
+// thread waits on the HIP event, nothing ever blocks the event loop (SURVEY.md 8b "Threading").
+struct PipeMsg {
+    int64_t window;
+    int32_t status;
+    std::vector<leon_pipeline_frame> frames;
+};
+
+struct PipeHandle {
+    leon_pipeline* p = nullptr;
+    napi_threadsafe_function tsfn = nullptr;
+    napi_ref stream_ref = nullptr;          // keeps the stream's Buffer alive: the pipeline reads it in place
+    std::mutex mu;
+    std::map<int64_t, std::vector<leon_pipeline_frame>> out;   // delivered, not yet released
+    leon_pipeline_info info{};
+};
+
+void pipe_native_cb(void* user, int64_t window, const leon_pipeline_frame* frames, int32_t n, int32_t status)
+{
+    PipeHandle* h = (PipeHandle*)user;
+    PipeMsg* m = new PipeMsg();
+    m->window = window;
+    m->status = status;
+    if (frames && n > 0) m->frames.assign(frames, frames + n);
+    if (window >= 0) {
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->out[window] = m->frames;
+    }
+    napi_call_threadsafe_function(h->tsfn, m, napi_tsfn_blocking);
+}
+
+void pipe_call_js(napi_env env, napi_value js_cb, void* ctx, void* data)
+{
+    PipeHandle* h = (PipeHandle*)ctx;
+    PipeMsg* m = (PipeMsg*)data;
+    if (env && js_cb) {
+        napi_value argv[3], undef, ret;
+        napi_create_int64(env, m->window, &argv[0]);
+        napi_create_array_with_length(env, m->frames.size(), &argv[1]);
+        for (size_t i = 0; i < m->frames.size(); i++) {
+            napi_value o, v;
+            napi_create_object(env, &o);
+            napi_create_double(env, (double)m->frames[i].gop, &v); napi_set_named_property(env, o, "gop", v);
+            napi_create_int32(env, m->frames[i].display_index, &v); napi_set_named_property(env, o, "displayIndex", v);
+            napi_create_int32(env, m->frames[i].type, &v); napi_set_named_property(env, o, "type", v);
+            napi_create_double(env, m->frames[i].ts_ms, &v); napi_set_named_property(env, o, "ts", v);
+            napi_set_element(env, argv[1], (uint32_t)i, o);
+        }
+        napi_create_int32(env, m->status, &argv[2]);
+        napi_get_undefined(env, &undef);
+        napi_call_function(env, undef, js_cb, 3, argv, &ret);
+    }
+    const bool ended = m->window < 0;
+    delete m;
+    if (ended && h->tsfn) {          // nothing more will come: let the event loop end
+        napi_release_threadsafe_function(h->tsfn, napi_tsfn_release);
+        h->tsfn = nullptr;
+    }
+}
+
+void pipe_finalize(napi_env env, void* data, void*)
+{
+    PipeHandle* h = (PipeHandle*)data;
+    if (h->p) leon_pipeline_destroy(h->p);
+    if (h->stream_ref) napi_delete_reference(env, h->stream_ref);
+    delete h;
+}
+
+PipeHandle* pipe_unwrap(napi_env env, napi_callback_info info, size_t* argc, napi_value* argv)
+{
+    napi_value self;
+    if (napi_get_cb_info(env, info, argc, argv, &self, nullptr) != napi_ok) return nullptr;
+    PipeHandle* h = nullptr;
+    if (napi_unwrap(env, self, (void**)&h) != napi_ok || !h || !h->p) {
+        napi_throw_error(env, nullptr, "pipeline is destroyed");
+        return nullptr;
+    }
+    return h;
+}
+
+napi_value PipeRelease(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1];
+    PipeHandle* h = pipe_unwrap(env, info, &argc, argv);
+    if (!h) return nullptr;
+    int64_t w = -1;
+    if (argc < 1 || napi_get_value_int64(env, argv[0], &w) != napi_ok) {
+        napi_throw_type_error(env, nullptr, "releaseWindow(window)");
+        return nullptr;
+    }
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        h->out.erase(w);
+    }
+    int rc = leon_pipeline_release_window(h->p, w);
+    return rc == LEON_OK ? nullptr : throw_leon(env, rc);
+}
+
+napi_value PipeReadFrame(napi_env env, napi_callback_info info)
+{
+    size_t argc = 2;
+    napi_value argv[2];
+    PipeHandle* h = pipe_unwrap(env, info, &argc, argv);
+    if (!h) return nullptr;
+    int64_t w = -1;
+    int32_t i = -1;
+    if (argc < 2 || napi_get_value_int64(env, argv[0], &w) != napi_ok || napi_get_value_int32(env, argv[1], &i) != napi_ok) {
+        napi_throw_type_error(env, nullptr, "readFrame(window, index)");
+        return nullptr;
+    }
+    leon_pipeline_frame f{};
+    {
+        std::lock_guard<std::mutex> lk(h->mu);
+        auto it = h->out.find(w);
+        if (it == h->out.end() || i < 0 || (size_t)i >= it->second.size()) {
+            napi_throw_range_error(env, nullptr, "readFrame: no such frame (window released?)");
+            return nullptr;
+        }
+        f = it->second[(size_t)i];
+    }
+    const size_t bytes = (size_t)h->info.frame_width * h->info.frame_height * 4;
+    napi_value ab, ta;
+    void* data = nullptr;
+    NAPI_OK(napi_create_arraybuffer(env, bytes, &data, &ab));
+    NAPI_OK(napi_create_typedarray(env, napi_uint8_array, bytes, ab, 0, &ta));
+    int rc = leon_pipeline_read_frame(h->p, &f, (uint8_t*)data);
+    return rc == LEON_OK ? ta : throw_leon(env, rc);
+}
+
+napi_value PipeStats(napi_env env, napi_callback_info info)
+{
+    size_t argc = 0;
+    PipeHandle* h = pipe_unwrap(env, info, &argc, nullptr);
+    if (!h) return nullptr;
+    leon_pipeline_stats s{};
+    leon_pipeline_get_stats(h->p, &s);
+    napi_value o, v;
+    NAPI_OK(napi_create_object(env, &o));
+    const struct { const char* k; double val; } kv[] = {
+        {"pictures", (double)s.pictures}, {"gops", (double)s.gops}, {"windows", (double)s.windows}, {"streamBytes", (double)s.stream_bytes},
+        {"seconds", s.seconds}, {"parseSecondsSum", s.parse_seconds_sum}, {"uploadBytes", s.upload_bytes}, {"entries", (double)s.entries},
+        {"frameWidth", (double)h->info.frame_width}, {"frameHeight", (double)h->info.frame_height},
+        {"codedWidth", (double)h->info.coded_width}, {"codedHeight", (double)h->info.coded_height},
+        {"pictureRate", h->info.picture_rate}, {"keyMapGops", (double)h->info.gops}, {"parserThreads", (double)h->info.parser_threads},
+        {"gopsPerWindow", (double)h->info.gops_per_window}};
+    for (auto& e : kv) {
+        NAPI_OK(napi_create_double(env, e.val, &v));
+        NAPI_OK(napi_set_named_property(env, o, e.k, v));
+    }
+    return o;
+}
+
+napi_value PipeDestroy(napi_env env, napi_callback_info info)
+{
+    napi_value self;
+    size_t argc = 0;
+    NAPI_OK(napi_get_cb_info(env, info, &argc, nullptr, &self, nullptr));
+    PipeHandle* h = nullptr;
+    if (napi_unwrap(env, self, (void**)&h) == napi_ok && h && h->p) {
+        leon_pipeline_destroy(h->p);       // joins the notify thread: no further callbacks are queued
+        h->p = nullptr;
+        if (h->tsfn) {
+            napi_release_threadsafe_function(h->tsfn, napi_tsfn_abort);
+            h->tsfn = nullptr;
+        }
+    }
+    return nullptr;
+}
+
+napi_value CreatePipeline(napi_env env, napi_callback_info info)
+{
+    size_t argc = 3;
+    napi_value argv[3];
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+    bool is_buf = false;
+    if (argc >= 1) napi_is_buffer(env, argv[0], &is_buf);
+    napi_valuetype cbt = napi_undefined;
+    if (argc >= 3) napi_typeof(env, argv[2], &cbt);
+    if (argc < 3 || !is_buf || cbt != napi_function) {
+        napi_throw_type_error(env, nullptr, "createPipeline(streamBuffer, options, callback)");
+        return nullptr;
+    }
+    void* data = nullptr;
+    size_t len = 0;
+    NAPI_OK(napi_get_buffer_info(env, argv[0], &data, &len));
+    leon_pipeline_config cfg;
+    memset(&cfg, 0, sizeof cfg);
+    bool ok = get_i32(env, argv[1], "deviceId", &cfg.device_id, 0) && get_i32(env, argv[1], "parserThreads", &cfg.parser_threads, 0) &&
+              get_i32(env, argv[1], "gopsPerWindow", &cfg.gops_per_window, 0) && get_i32(env, argv[1], "windowsInFlight", &cfg.windows_in_flight, 0) &&
+              get_i32(env, argv[1], "maxGopPictures", &cfg.max_gop_pictures, 0) && get_i32(env, argv[1], "loop", &cfg.loop, 0);
+    if (!ok) {
+        napi_throw_type_error(env, nullptr, "createPipeline: integer options expected");
+        return nullptr;
+    }
+    PipeHandle* h = new PipeHandle();
+    napi_value name;
+    NAPI_OK(napi_create_string_utf8(env, "leon pipeline frames", NAPI_AUTO_LENGTH, &name));
+    if (napi_create_threadsafe_function(env, argv[2], nullptr, name, 0, 1, nullptr, nullptr, h, pipe_call_js, &h->tsfn) != napi_ok) {
+        delete h;
+        napi_throw_error(env, nullptr, "napi_create_threadsafe_function failed");
+        return nullptr;
+    }
+    napi_create_reference(env, argv[0], 1, &h->stream_ref);
+    int rc = leon_pipeline_create(&cfg, (const uint8_t*)data, len, pipe_native_cb, h, &h->p);
+    if (rc != LEON_OK) {
+        napi_release_threadsafe_function(h->tsfn, napi_tsfn_abort);
+        napi_delete_reference(env, h->stream_ref);
+        delete h;
+        return throw_leon(env, rc);
+    }
+    leon_pipeline_get_info(h->p, &h->info);
+    napi_value obj;
+    NAPI_OK(napi_create_object(env, &obj));
+    NAPI_OK(napi_wrap(env, obj, h, pipe_finalize, nullptr, nullptr));
+    const struct { const char* name; napi_callback fn; } methods[] = {
+        {"releaseWindow", PipeRelease}, {"readFrame", PipeReadFrame}, {"stats", PipeStats}, {"destroy", PipeDestroy}};
+    for (auto& m : methods) {
+        napi_value fn;
+        NAPI_OK(napi_create_function(env, m.name, NAPI_AUTO_LENGTH, m.fn, nullptr, &fn));
+        NAPI_OK(napi_set_named_property(env, obj, m.name, fn));
+    }
+    return obj;
+}
+
 napi_value AbiVersion(napi_env env, napi_callback_info)
 {
     napi_value v;
@@ -357,6 +592,8 @@ napi_value Init(napi_env env, napi_value exports)
     napi_value fn;
     NAPI_OK(napi_create_function(env, "create", NAPI_AUTO_LENGTH, Create, nullptr, &fn));
     NAPI_OK(napi_set_named_property(env, exports, "create", fn));
+    NAPI_OK(napi_create_function(env, "createPipeline", NAPI_AUTO_LENGTH, CreatePipeline, nullptr, &fn));
+    NAPI_OK(napi_set_named_property(env, exports, "createPipeline", fn));
     NAPI_OK(napi_create_function(env, "abiVersion", NAPI_AUTO_LENGTH, AbiVersion, nullptr, &fn));
     NAPI_OK(napi_set_named_property(env, exports, "abiVersion", fn));
     return exports;

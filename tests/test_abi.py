@@ -7,8 +7,8 @@ import re
 from helpers import ROOT
 
 
-def _declared():
-    txt = open(os.path.join(ROOT, "include", "leon.h")).read()
+def _declared(header="leon.h"):
+    txt = open(os.path.join(ROOT, "include", header)).read()
     txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
     return sorted(set(re.findall(r"\b(leon_[a-z0-9_]+)\s*\(", txt)))
 
@@ -22,6 +22,10 @@ def test_header_symbols_all_exported():
         assert hasattr(lib, n), "libleon_hip.so does not export %s" % n
     assert set(names) == set(L.SYMBOLS)
     assert lib.leon_abi_version() == 2
+    pipe = [n for n in _declared("leon_pipeline.h") if n.startswith("leon_pipeline_") and n not in ("leon_pipeline_callback",)]
+    assert set(pipe) == set(L.PIPELINE_SYMBOLS), set(pipe) ^ set(L.PIPELINE_SYMBOLS)
+    for n in pipe:
+        assert hasattr(lib, n), "libleon_hip.so does not export %s" % n
 
 
 def test_struct_layouts():

@@ -1,0 +1,167 @@
+"""GPU: the native decode pipeline (include/leon_pipeline.h) -- stream bytes in, RGBA frames in device
+memory out, K parser threads / one launch per picture type and dependency level across a window of GOPs /
+fused display conversion -- against the oracle run picture by picture on the same stream."""
+import os
+import threading
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+STREAMS = os.path.join(ROOT, "tests", "golden", "streams")
+
+
+@pytest.fixture(scope="module")
+def L():
+    import leon_ctypes
+    leon_ctypes.load()
+    return leon_ctypes
+
+
+def oracle_frames(data):
+    """{(gop, display_index): RGBA} by parsing with the native front end and decoding with the oracle"""
+    import leon_vlc_ctypes as V
+    from oracle import oracle_py as O
+    st = V.Stream(data, threads=1)
+    info = st.info
+    cw, ch, fw, fh = info.coded_width, info.coded_height, info.frame_width, info.frame_height
+    qm = np.concatenate([np.frombuffer(bytes(info.intra_qm), np.uint8), np.frombuffer(bytes(info.non_intra_qm), np.uint8)])
+    out = {}
+    gop = -1
+    older = newer = None
+    while True:
+        p = st.next_picture(dense=True)
+        if p is None:
+            break
+        if p["type"] == 1:
+            gop += 1
+            older = newer = None
+        fwd = bwd = None
+        if p["type"] == 2:
+            fwd = newer
+        elif p["type"] == 3:
+            bwd, fwd = newer, (older if older is not None else newer)
+        planes = O.decode_picture(p["type"], cw, ch, p["coef_y"], p["coef_cb"], p["coef_cr"], p["qscale"], p["intra"],
+                                  repadd=p.get("repadd"), mb_dir=p.get("mb_dir"), mv_fwd=p.get("mv_fwd"), mv_bwd=p.get("mv_bwd"),
+                                  qm=qm, ref_fwd=fwd, ref_bwd=bwd)
+        if p["type"] != 3:
+            older, newer = newer, planes
+        y, cb, cr = O.split_planes(planes, cw, ch)
+        out[(gop, p["temporal_reference"])] = O.ycbcr_to_rgba(y, cb, cr, cw, fw, fh, "cpu")
+    return out
+
+
+def run_pipeline(L, data, **kw):
+    got = {}
+    order = []
+
+    def on_window(window, frames):
+        for f in frames:
+            got[(f["gop"], f["display_index"])] = pipe.read_frame(f)
+            order.append((f["gop"], f["display_index"], f["ts_ms"]))
+    pipe = L.Pipeline(data, on_window=on_window, **kw)
+    try:
+        pipe.wait()
+        assert pipe.ended and pipe.error is None
+        stats = pipe.stats()
+    finally:
+        pipe.close()
+    return got, order, stats
+
+
+def ibbp_stream(cw, ch, gops, seed):
+    import jsv_writer as W
+    import synth as S
+    rng = np.random.default_rng(seed)
+    pics, starts = [], []
+    for n in gops:
+        starts.append(len(pics))
+        for ptype, disp, f, b in S.gop_ibbp(n):
+            t = S.make_picture(rng, cw, ch, ptype, force_dir=2 if (ptype == S.PIC_B and f is None) else None)
+            t["display"] = disp
+            pics.append(t)
+    return W.write_stream(pics, cw, ch, cw, ch, gop_starts=starts)[0]
+
+
+@pytest.mark.parametrize("name", ["leon_synth_352x240", "slices5_ip_96x64", "custom_intra_ip_48x32", "tiny_ip_32x32"])
+def test_fixture_streams(L, name):
+    data = open(os.path.join(STREAMS, name + ".jsv"), "rb").read()
+    want = oracle_frames(data)
+    got, order, stats = run_pipeline(L, data, parser_threads=3, gops_per_window=2)
+    assert set(got) == set(want) and stats["pictures"] == len(want)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), "%s: frame %s differs" % (name, k)
+    assert order == sorted(order)                       # GOP-major, display order inside a GOP
+
+
+@pytest.mark.parametrize("window,threads,inflight", [(1, 1, 1), (3, 4, 2), (8, 2, 3)])
+def test_ibbp_windows_and_loops(L, window, threads, inflight):
+    """7 GOPs of different lengths (IBBP, closed): every window / thread / ring geometry gives the oracle's frames,
+    and looping the stream continues the GOP numbering"""
+    data = ibbp_stream(96, 64, [12, 6, 9, 12, 3, 12, 7], seed=4242)
+    want = oracle_frames(data)
+    got, order, stats = run_pipeline(L, data, parser_threads=threads, gops_per_window=window, windows_in_flight=inflight, loop=2)
+    assert len(got) == 2 * len(want) and stats["gops"] == 14 and stats["pictures"] == 2 * len(want)
+    for (g, d), img in want.items():
+        assert np.array_equal(got[(g, d)], img), (g, d)
+        assert np.array_equal(got[(g + 7, d)], img), (g + 7, d)
+    ts = [t for _, _, t in order[:61]]
+    assert ts == sorted(ts) and ts[1] - ts[0] == pytest.approx(40.0)      # 25 pictures/s
+
+
+def test_consumer_may_hold_windows(L):
+    """frames stay valid until the window is released, from any thread; the pipeline waits for its ring"""
+    data = ibbp_stream(96, 64, [6] * 6, seed=7)
+    want = oracle_frames(data)
+    held = []
+    got = {}
+    lock = threading.Lock()
+
+    def on_window(window, frames):
+        with lock:
+            held.append((window, frames))
+        return False                                     # keep it
+    pipe = L.Pipeline(data, on_window=on_window, parser_threads=2, gops_per_window=2, windows_in_flight=2)
+    try:
+        import time
+        released = 0
+        while released < 3:
+            time.sleep(0.05)
+            with lock:
+                batch, held[:] = list(held), []
+            for window, frames in batch:
+                for f in frames:
+                    got[(f["gop"], f["display_index"])] = pipe.read_frame(f)
+                pipe.release_window(window)
+                released += 1
+        pipe.wait()
+    finally:
+        pipe.close()
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+
+
+def test_pipeline_errors(L):
+    data = open(os.path.join(STREAMS, "ibbp_96x64.jsv"), "rb").read()        # frame 90 x 60
+    with pytest.raises(L.LeonError) as e:
+        L.Pipeline(data)
+    assert "frame_width % 8" in str(e.value)
+    with pytest.raises(L.LeonError):
+        L.Pipeline(b"\x00" * 64)
+    # a damaged GOP: the run stops with an error instead of delivering garbage
+    good = ibbp_stream(96, 64, [6, 6, 6], seed=9)
+    bad = bytearray(good)
+    import leon_vlc_ctypes as V
+    offs = V.Stream(good, threads=1).keymap()
+    for i in range(offs[1] + 60, offs[1] + 400):
+        bad[i] = 0xFF
+    pipe = L.Pipeline(bytes(bad), gops_per_window=1, parser_threads=1, max_gop_pictures=64)
+    try:
+        with pytest.raises(L.LeonError):
+            pipe.wait()
+    finally:
+        pipe.close()

@@ -216,3 +216,27 @@ def test_slices_that_start_mid_row_and_span_rows(slice_mbs, tmp_path):
                 assert sha(p["mv_fwd"]) == j["sha"]["mvFwd"] and sha(p["repadd"]) == j["sha"]["repadd"], (threads, i)
             if p["type"] == 3:
                 assert sha(p["mv_bwd"]) == j["sha"]["mvBwd"] and sha(p["mb_dir"]) == j["sha"]["mbDir"], (threads, i)
+
+
+@pytest.mark.parametrize("name", ["leon_synth_352x240", "ibbp_96x64"])
+def test_gop_shards_parse_like_the_whole_stream(name):
+    """a stream opened on the bytes of ONE key-map entry (a GOP shard, starting with its 00 00 01 C3
+    sequence header) gives exactly that GOP's pictures -- the unit the pipeline's parser threads and the
+    multi-GPU partition work on (decoders/jsv.js:264-350)"""
+    data = read(name)
+    whole_st, whole = all_pictures(data, threads=1)
+    offs = whole_st.keymap()
+    assert len(offs) == whole_st.info.keymap_count >= 2
+    got = []
+    for g, b in enumerate(offs):
+        e = offs[g + 1] if g + 1 < len(offs) else len(data)
+        assert data[b:b + 4] == b"\x00\x00\x01\xc3"
+        _, pics = all_pictures(data[b:e], threads=1)
+        assert pics and pics[0]["type"] == 1
+        got += pics
+    assert len(got) == len(whole)
+    for i, (a, b) in enumerate(zip(got, whole)):
+        assert a["type"] == b["type"] and a["temporal_reference"] == b["temporal_reference"], i
+        for k in ("coef_y", "coef_cb", "coef_cr", "repadd", "mv_fwd", "mv_bwd", "mb_dir"):
+            if b.get(k) is not None:
+                assert np.array_equal(a[k], b[k]), (i, k)
