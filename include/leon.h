@@ -70,6 +70,13 @@ typedef struct leon_config {
     int32_t n_slots;       /* output ring; the reference uses 13 (jsv.js:24, :58-73) */
     int32_t device_id;     /* HIP device ordinal */
     void*   stream;        /* hipStream_t to run on, or NULL: the decoder owns one */
+    int32_t alpha;         /* ABI 2: yuva stream (container flag `a`, decoders/jsv.js:256-259): every slot gets a fourth,
+                              luma-sized plane [Y|Cb|Cr|A] like the reference's 4-plane ring (jsv.js:59-73); pictures
+                              carry coef_a; RGBA output takes its A byte from the plane.  The reference allocates the
+                              plane and never decodes it (IDCT_GL loops over three components, jsv.js:1223): A is
+                              reconstructed like luma here -- same maps, luma vectors, same matrices.  Needs an even
+                              frame width; not available with the fused display conversion. */
+    int32_t reserved;
 } leon_config;
 
 typedef struct leon_picture {
@@ -95,6 +102,7 @@ typedef struct leon_picture {
     void*   rgba_out;
     int32_t no_planes;
     int32_t reserved;
+    const int16_t* coef_a; /* yuva decoders (leon_config.alpha): the A plane's raw levels, coded-luma size; else NULL */
 } leon_picture;
 
 /* The same picture with its coefficients as sparse per-group lists -- the format the native
@@ -103,7 +111,8 @@ typedef struct leon_picture {
  * listed position and 0 elsewhere.  Lists and maps live where `mem` of the call says. */
 typedef struct leon_sparse_picture {
     int32_t type, out_slot, ref_fwd_slot, ref_bwd_slot;
-    const uint32_t* grp_off;   /* [n_groups+1], n_groups = 2*mbH*ceil(2*mbW/8) + 2*mbH*ceil(mbW/8) */
+    const uint32_t* grp_off;   /* [n_groups+1], n_groups = 2*mbH*ceil(2*mbW/8) + 2*mbH*ceil(mbW/8); yuva decoders: the A
+                                  plane's 2*mbH*ceil(2*mbW/8) groups follow, numbered like the luma groups */
     const uint32_t* entries;   /* [n_entries]: (tile byte offset r*128+b*16+c*2) << 16 | (uint16)level */
     uint32_t n_entries;
     int32_t reserved;
@@ -187,6 +196,9 @@ int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, vo
  * decoders/jsv.js:1141-1159 is its only analogue) */
 int leon_read_planes(leon_decoder* d, int32_t slot, uint8_t* y, uint8_t* cb, uint8_t* cr);
 int leon_write_planes(leon_decoder* d, int32_t slot, const uint8_t* y, const uint8_t* cb, const uint8_t* cr);
+/* the fourth plane of a yuva decoder's slot (coded-luma size) */
+int leon_read_alpha_plane(leon_decoder* d, int32_t slot, uint8_t* a);
+int leon_write_alpha_plane(leon_decoder* d, int32_t slot, const uint8_t* a);
 /* device address of a slot's [Y|Cb|Cr] planes (for zero-copy consumers) */
 int leon_slot_device_ptr(leon_decoder* d, int32_t slot, void** ptr, size_t* bytes);
 

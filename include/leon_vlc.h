@@ -20,6 +20,10 @@
  *     Cb     block row R (0 .. mb_height-1)            :  n_y + R*groups_c + g
  *     Cr                                               :  n_y + n_c + R*groups_c + g
  *   with n_y = 2*mb_height*groups_y, n_c = mb_height*groups_c, n_groups = n_y + 2*n_c.
+ *   yuva streams (container flag `a` = 1, leon_vlc_info.has_alpha): the A component -- four more blocks per
+ *   macroblock, placed and coded like the luma blocks (syntax: tools/jsv_writer.py write_picture; the reference
+ *   reads the flag, decoders/jsv.js:256-259, and defines no syntax) -- adds n_y groups numbered like the luma
+ *   ones:   A  block row R, group g :  n_y + 2*n_c + R*groups_y + g      (n_groups = 2*n_y + 2*n_c)
  *   grp_off[n_groups+1] are prefix offsets into entries[]; the entries of a group are
  *   contiguous, in no particular order.  One entry = one non-zero level:
  *     bits  0..15  level (int16; intra DC in the 0..255 predictor domain, jsv.js:1346-1443)
@@ -109,6 +113,8 @@ int leon_vlc_get_keymap(leon_vlc_stream* s, uint32_t* byte_offsets, uint32_t* ti
 
 /* sparse lists -> the dense int16 planes the reference uploads (planes are overwritten) */
 int leon_vlc_densify(const leon_vlc_info* info, const leon_vlc_picture* pic, int16_t* y, int16_t* cb, int16_t* cr);
+/* the A plane of a yuva picture (coded-luma size) */
+int leon_vlc_densify_alpha(const leon_vlc_info* info, const leon_vlc_picture* pic, int16_t* a);
 
 #ifdef __cplusplus
 }

@@ -200,17 +200,20 @@ void upload_tables(leon_decoder* d)
         }
 }
 
-int n_groups_of(const Geom& G) { return 2 * G.tasksY + 2 * G.tasksC; }
+int n_groups_of(const Geom& G) { return 2 * G.tasksY + 2 * G.tasksC + (G.alpha ? 2 * G.tasksY : 0); }
 
 // Algorithmic bytes of one picture's reconstruction (dense boundary) from its own maps.  Maps in
 // device memory are read back (synchronously: only prepared batches and timed ad-hoc submits ask).
 int algo_bytes_of(leon_decoder* d, const leon_picture& p, bool device_maps, double& bytes)
 {
+    // yuva: the A plane is a second luma -- 4 of a macroblock's 10 blocks -- priced like the 4 luma blocks:
+    // (512 coefficients + 256 written [+ 256 per reference]) on top of the 6-block figures below
     const size_t mbs = (size_t)d->geom.mbw * d->geom.mbh;
     // fused display conversion: + 1024 B of RGBA per macroblock, - the 384 B of planes when they are not written
     const double disp = p.rgba_out ? (1024.0 - (p.no_planes ? 384.0 : 0.0)) * (double)mbs : 0.0;
+    const double a_base = d->geom.alpha ? 768.0 * (double)mbs : 0.0, a_ref = d->geom.alpha ? 256.0 : 0.0;
     if (p.type == LEON_PIC_I) {
-        bytes = kBytesI * (double)mbs + disp;
+        bytes = kBytesI * (double)mbs + disp + a_base;
         return LEON_OK;
     }
     std::vector<uint8_t> rep(mbs), dir;
@@ -229,7 +232,7 @@ int algo_bytes_of(leon_decoder* d, const leon_picture& p, bool device_maps, doub
         if (rp[i] >= 128) continue;                                    // replace: no prediction
         refs += p.type == LEON_PIC_P ? 1u : (uint64_t)((dp[i] & 1) + ((dp[i] >> 1) & 1));
     }
-    bytes = (p.type == LEON_PIC_P ? kBytesPBase : kBytesBBase) * (double)mbs + kBytesRef * (double)refs + disp;
+    bytes = (p.type == LEON_PIC_P ? kBytesPBase : kBytesBBase) * (double)mbs + (kBytesRef + a_ref) * (double)refs + disp + a_base;
     return LEON_OK;
 }
 
@@ -242,9 +245,11 @@ int check_pic(const leon_decoder* d, const AnyPic& a)
         return fail(LEON_ERR_INVALID, "out_slot %d", p.out_slot);
     if (a.sparse) {
         if (!a.grp_off || (!a.entries && a.n_entries) || !p.qscale || !p.intra) return fail(LEON_ERR_INVALID, "null boundary tensor");
-        if (a.n_entries > (uint32_t)d->geom.cw * (uint32_t)d->geom.ch * 3u / 2u)
+        if (a.n_entries > (uint32_t)d->geom.cw * (uint32_t)d->geom.ch * (d->geom.alpha ? 5u : 3u) / 2u)
             return fail(LEON_ERR_INVALID, "%u entries exceed the coefficient count of a picture", a.n_entries);
     } else if (!p.coef_y || !p.coef_cb || !p.coef_cr || !p.qscale || !p.intra) return fail(LEON_ERR_INVALID, "null boundary tensor");
+    else if (d->geom.alpha && !p.coef_a) return fail(LEON_ERR_INVALID, "a yuva decoder needs coef_a");
+    if (d->geom.alpha && p.rgba_out) return fail(LEON_ERR_INVALID, "the fused display conversion is not available for yuva decoders");
     if (p.type != LEON_PIC_I) {
         if (p.ref_fwd_slot < 0 || p.ref_fwd_slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "ref_fwd_slot %d", p.ref_fwd_slot);
         if (!p.repadd || !p.mv_fwd) return fail(LEON_ERR_INVALID, "P/B picture without repadd/mv_fwd");
@@ -271,6 +276,7 @@ void fill_desc(const leon_decoder* d, const AnyPic& a, PicDesc& o)
     o.coef[0] = p.coef_y;
     o.coef[1] = p.coef_cb;
     o.coef[2] = p.coef_cr;
+    o.coef[3] = p.coef_a;
     o.qscale = p.qscale;
     o.intra = p.intra;
     o.repadd = p.repadd;
@@ -425,6 +431,7 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
     if (cfg->frame_width <= 0 || cfg->frame_height <= 0 || cfg->frame_width > cfg->coded_width || cfg->frame_height > cfg->coded_height)
         return fail(LEON_ERR_INVALID, "frame size %dx%d", cfg->frame_width, cfg->frame_height);
     if (cfg->n_slots < 1) return fail(LEON_ERR_INVALID, "n_slots %d", cfg->n_slots);
+    if (cfg->alpha && (cfg->frame_width & 1)) return fail(LEON_ERR_INVALID, "a yuva decoder needs an even frame width (it is %d)", cfg->frame_width);
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev == 0)
         return fail(LEON_ERR_NO_DEVICE, "no HIP device: this library has no CPU fallback");
@@ -457,7 +464,8 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
     G.gC = ((G.cw >> 4) + 7) >> 3;
     G.tasksY = G.gY * G.mbh;            // one task = both block rows of a macroblock row
     G.tasksC = G.gC * G.mbh;            // one task = the Cb and the Cr group of a block row
-    G.tasks_per_pic = G.tasksY + G.tasksC;
+    G.alpha = cfg->alpha ? 1 : 0;
+    G.tasks_per_pic = G.tasksY + G.tasksC + (G.alpha ? G.tasksY : 0);   // yuva: the A plane's luma-shaped tasks last
     G.wg_per_pic = (G.tasks_per_pic + kWavesPerWG - 1) / kWavesPerWG;
     auto inv32 = [](uint32_t dv) { return (uint32_t)(((1ull << 32) + dv - 1) / dv); };   // exact for n*dv < 2^32
     G.inv_wg_per_pic = G.wg_per_pic == 1 ? 0u : inv32((uint32_t)G.wg_per_pic);
@@ -465,7 +473,7 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
     G.inv_gC = G.gC == 1 ? 0u : inv32((uint32_t)G.gC);
     G.fw = cfg->frame_width;
     G.fh = cfg->frame_height;
-    d->plane_bytes = (size_t)G.cw * G.ch * 3 / 2;
+    d->plane_bytes = (size_t)G.cw * G.ch * (G.alpha ? 5 : 3) / 2;
     d->slot_stride = (d->plane_bytes + 255) / 256 * 256 + 256;   // tail pad: the 12-byte MC window may over-read 3 bytes
     d->inuse.assign(cfg->n_slots, 0);
     auto bail = [&](const char* what) {
@@ -487,7 +495,7 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
     // staging for host-memory pictures: coef planes (2 bytes/sample) + 5 byte maps + 2 vector maps
     size_t mbs = (size_t)G.mbw * G.mbh;
     // coefficients: dense planes (2 B each) or, at worst, one 4-byte entry each plus the group offsets
-    d->stage_bytes = d->plane_bytes * 4 + ((size_t)n_groups_of(d->geom) + 1) * 4 + 1024 + 4 * ((mbs + 255) / 256 * 256) + 2 * ((mbs * 4 + 255) / 256 * 256) + 1024;
+    d->stage_bytes = d->plane_bytes * 4 + (G.alpha ? (size_t)G.cw * G.ch * 2 : 0) + ((size_t)n_groups_of(d->geom) + 1) * 4 + 1024 + 4 * ((mbs + 255) / 256 * 256) + 2 * ((mbs * 4 + 255) / 256 * 256) + 1024;
     if (hipStreamSynchronize(d->stream) != hipSuccess) return bail("create sync");
     *out = d;
     return LEON_OK;
@@ -617,6 +625,7 @@ int submit_picture_any(leon_decoder* d, const AnyPic& pic)
         dp.p.coef_y = (const int16_t*)put(pic.p.coef_y, ny * 2, ny * 2);
         dp.p.coef_cb = (const int16_t*)put(pic.p.coef_cb, nc * 2, nc * 2);
         dp.p.coef_cr = (const int16_t*)put(pic.p.coef_cr, nc * 2, nc * 2);
+        dp.p.coef_a = (const int16_t*)put(G.alpha ? pic.p.coef_a : nullptr, ny * 2, G.alpha ? ny * 2 : 0);
     }
     const int type = pic.p.type;
     dp.p.qscale = (const uint8_t*)put(pic.p.qscale, mbs, mpad);
@@ -883,6 +892,14 @@ int leon_convert_rgba_batch(leon_decoder* d, const int32_t* slots, int32_t n, vo
         hipLaunchKernelGGL(k_rgba_gl, dim3((G.fw + kRgbaBlock - 1) / kRgbaBlock, G.fh, n), dim3(kRgbaBlock), 0, cs,
                            d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G);
     }
+    if (d->geom.alpha) {
+        // yuva: A bytes from the fourth plane, over what the conversion wrote (the CPU twin's quad loop covers
+        // whole quads only; the GL flavour every pixel)
+        const int cover_w = flavour == LEON_RGB_CPU_TWIN ? (G.fw >> 1) * 2 : G.fw, cover_h = flavour == LEON_RGB_CPU_TWIN ? (G.fh >> 1) * 2 : G.fh;
+        if (cover_w > 0 && cover_h > 0)
+            hipLaunchKernelGGL(k_rgba_alpha, dim3((cover_w / 2 + kRgbaBlock - 1) / kRgbaBlock, cover_h, n), dim3(kRgbaBlock), 0, cs,
+                               d->d_slots, d->d_slot_ids + at, (uint8_t*)rgba_device, G, cover_w, cover_h);
+    }
     HIP_TRY(hipGetLastError());
     if (d->timing) {
         HIP_TRY(hipEventRecord(tl.b, cs));
@@ -934,6 +951,28 @@ int leon_write_planes(leon_decoder* d, int32_t slot, const uint8_t* y, const uin
     if (y) HIP_TRY(hipMemcpyAsync(base, y, ny, hipMemcpyHostToDevice, d->stream));
     if (cb) HIP_TRY(hipMemcpyAsync(base + ny, cb, nc, hipMemcpyHostToDevice, d->stream));
     if (cr) HIP_TRY(hipMemcpyAsync(base + ny + nc, cr, nc, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LEON_OK;
+}
+
+int leon_read_alpha_plane(leon_decoder* d, int32_t slot, uint8_t* a)
+{
+    if (!d || slot < 0 || slot >= d->cfg.n_slots || !a) return fail(LEON_ERR_INVALID, "slot %d", slot);
+    if (!d->geom.alpha) return fail(LEON_ERR_INVALID, "not a yuva decoder");
+    HIP_TRY(hipSetDevice(d->dev));
+    const size_t ny = (size_t)d->geom.cw * d->geom.ch;
+    HIP_TRY(hipMemcpyAsync(a, d->d_slots + (size_t)slot * d->slot_stride + ny + ny / 2, ny, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    return LEON_OK;
+}
+
+int leon_write_alpha_plane(leon_decoder* d, int32_t slot, const uint8_t* a)
+{
+    if (!d || slot < 0 || slot >= d->cfg.n_slots || !a) return fail(LEON_ERR_INVALID, "slot %d", slot);
+    if (!d->geom.alpha) return fail(LEON_ERR_INVALID, "not a yuva decoder");
+    HIP_TRY(hipSetDevice(d->dev));
+    const size_t ny = (size_t)d->geom.cw * d->geom.ch;
+    HIP_TRY(hipMemcpyAsync(d->d_slots + (size_t)slot * d->slot_stride + ny + ny / 2, a, ny, hipMemcpyHostToDevice, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
     return LEON_OK;
 }

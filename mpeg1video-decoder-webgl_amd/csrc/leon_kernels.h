@@ -41,7 +41,7 @@
 namespace leon {
 
 struct PicDesc {                 // one per picture of a batch, device resident
-    const int16_t* coef[3];      // T1: Y, Cb, Cr raw levels
+    const int16_t* coef[4];      // T1: Y, Cb, Cr raw levels (+ A of a yuva stream)
     const uint8_t* qscale;       // T2
     const uint8_t* intra;        // T3
     const uint8_t* repadd;       // T4
@@ -72,7 +72,7 @@ struct Geom {
     uint32_t inv_wg_per_pic;     // ceil(2^32 / wg_per_pic)
     uint32_t inv_gY, inv_gC;     // ceil(2^32 / gY), ceil(2^32 / gC)
     int32_t fw, fh;              // display crop (fused display conversion)
-    int32_t pad_;
+    int32_t alpha;               // yuva: a fourth, luma-sized plane behind Cr; its tasks follow the chroma tasks
 };
 
 struct Tables {                  // T6, per sequence
@@ -533,14 +533,18 @@ __device__ __forceinline__ v4u rgba_row4(uint32_t y4, uint32_t cb2, uint32_t cr2
     return v4u{px[0], px[1], px[2], px[3]};
 }
 
+// `alpha` (wave-uniform, luma-shaped tasks only): the task reconstructs the A plane of a yuva picture --
+// the same code path as luma with its own coefficient plane, the plane behind Cr in every slot, and the
+// alpha groups of the sparse lists.
 template <int TYPE, bool CHROMA, bool SPARSE, bool DISPLAY>
 __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, const Tables* __restrict__ Tg,
-                                           int Rt, int g, char* lds, int lane, Display dsp)
+                                           int Rt, int g, char* lds, int lane, Display dsp, bool alpha = false)
 {
     const int W = CHROMA ? G.cw >> 1 : G.cw;
     const int H = CHROMA ? G.ch >> 1 : G.ch;
     const int bw = W >> 3;
     const uint32_t ysz = (uint32_t)G.cw * (uint32_t)G.ch;
+    const uint32_t a_off = !CHROMA && alpha ? ysz + (ysz >> 1) : 0u;       // byte offset of the A plane in a slot
     const LEON_GLOBAL Tables* T = gptr(Tg);
     const int hi3 = lane >> 3, lo3 = lane & 7;
 
@@ -572,7 +576,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         (void*)(SPARSE ? pd.entries : nullptr), 0, SPARSE ? (int)(pd.n_entries * 4u) : 0, 0x00020000);
     if constexpr (SPARSE) {
         const uint32_t nY = 2u * (uint32_t)G.tasksY, nC = (uint32_t)G.tasksC;
-        const uint32_t gid0 = CHROMA ? nY + (uint32_t)(Rt * G.gC + g) : (uint32_t)(2 * Rt * G.gY + g);
+        const uint32_t gid0 = CHROMA ? nY + (uint32_t)(Rt * G.gC + g) : (uint32_t)(2 * Rt * G.gY + g) + (alpha ? nY + 2u * nC : 0u);
         const uint32_t gid1 = CHROMA ? gid0 + nC : gid0 + (uint32_t)G.gY;
         const uint32_t* go = pd.grp_off;                     // wave-uniform index: scalar loads
         const uint32_t gid[2] = {gid0, gid1};
@@ -585,7 +589,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
                 ent_rs, (int)(((s0 + (uint32_t)lane) * 4u) | ((uint32_t)lane < ent_count[h] ? 0u : kOobBit)), 0, kAuxStreamOnce);
         }
     } else {
-        cv_next = buf_load_v4i_s(buf_rsrc(pd.coef[CHROMA ? 1 : 0]), coef_voff, 0u);
+        cv_next = buf_load_v4i_s(buf_rsrc(pd.coef[CHROMA ? 1 : (alpha ? 3 : 0)]), coef_voff, 0u);
     }
     const v2u mI = ldg<v2u>(T, (uint32_t)c * 8u), mN = ldg<v2u>(T, 64u + (uint32_t)c * 8u);
     const v2u pm8 = ldg<v2u>(T, 128u + (uint32_t)c * 8u);
@@ -660,14 +664,14 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int Rh = CHROMA ? Rt : 2 * Rt + h;
-            const uint32_t po = CHROMA ? (h == 0 ? ysz : ysz + (ysz >> 2)) : 0u;
+            const uint32_t po = CHROMA ? (h == 0 ? ysz : ysz + (ysz >> 2)) : a_off;
             if (any_f) rfh[h] = fetch_rows(gptr(pd.ref_fwd) + po, W, H, 8 * Rh + hi3, pxA, ayA, ohA, ovA, inA, hi3 == 7, useA);
             if (TYPE == 3 && any_b) rbh[h] = fetch_rows(gptr(pd.ref_bwd) + po, W, H, 8 * Rh + hi3, pxB, ayB, ohB, ovB, inB, hi3 == 7, useB);
         }
     }
 #pragma unroll
     for (int half = 0; half < 2; half++) {
-        const uint32_t plane_off = CHROMA ? (half == 0 ? ysz : ysz + (ysz >> 2)) : 0u;
+        const uint32_t plane_off = CHROMA ? (half == 0 ? ysz : ysz + (ysz >> 2)) : a_off;
 
         // ---- stage 0: this half's coefficient rows were requested a half earlier; request the
         //      next half's now so that their HBM latency hides behind this half's arithmetic
@@ -675,7 +679,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         if constexpr (!SPARSE) {
             // always issued; in the last half the resource has no records, so nothing is fetched
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)pd.coef[CHROMA ? 2 : 0], 0, half == 0 ? 0x7fffffff : 0, 0x00020000);
+                (void*)pd.coef[CHROMA ? 2 : (alpha ? 3 : 0)], 0, half == 0 ? 0x7fffffff : 0, 0x00020000);
             cv_next = buf_load_v4i_s(rs, coef_voff, 2u * half_step);
         }
         RefRows rf = rfh[half], rb = rbh[half];
@@ -889,10 +893,14 @@ __device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G,
     if (t < G.tasksY) {
         int Rt = div_inv(t, G.inv_gY), g = t - Rt * G.gY;
         recon_task<TYPE, false, SPARSE, false>(pd, G, T, Rt, g, lds, lane, none);
-    } else {
+    } else if (t < G.tasksY + G.tasksC) {
         t -= G.tasksY;
         int Rt = div_inv(t, G.inv_gC), g = t - Rt * G.gC;
         recon_task<TYPE, true, SPARSE, false>(pd, G, T, Rt, g, lds, lane, none);
+    } else {                                   // yuva: the A plane, luma-shaped
+        t -= G.tasksY + G.tasksC;
+        int Rt = div_inv(t, G.inv_gY), g = t - Rt * G.gY;
+        recon_task<TYPE, false, SPARSE, false>(pd, G, T, Rt, g, lds, lane, none, true);
     }
 }
 
@@ -948,7 +956,7 @@ struct RgbaGeom {
     int32_t cw, ch, fw, fh;
     int32_t cols, rows;          // fw>>1, fh>>1 quads
     int32_t n;                   // frames in the batch
-    int32_t flavour;             // 0 CPU twin (fp64), 1 GL (fp32)
+    int32_t flavour;             // 0 CPU twin (fp64), 1 GL (fp32); bit 8: yuva -- the A byte comes from the slot's fourth plane
     uint32_t slot_stride_lo, slot_stride_hi;   // bytes between slots
     uint32_t inv_cols4;          // ceil(2^32 / (fw/4)): the 4x2 kernel walks a frame linearly
 };
@@ -1044,6 +1052,24 @@ __global__ __launch_bounds__(kRgbaBlock) void k_rgba_twin4(const uint8_t* __rest
     const uint32_t o = ((uint32_t)(2 * row) * (uint32_t)G.fw + 4u * (uint32_t)col4) * 4u;
     __builtin_amdgcn_raw_buffer_store_b128(v4u{o0[0], o0[1], o0[2], o0[3]}, rs, (int)o, 0, 0);
     __builtin_amdgcn_raw_buffer_store_b128(v4u{o1[0], o1[1], o1[2], o1[3]}, rs, (int)(o + (uint32_t)G.fw * 4u), 0, 0);
+}
+
+// yuva: the A byte of every converted pixel comes from the slot's fourth plane (behind Cr) instead of the
+// constant 255 -- a second pass over the frame, launched for alpha decoders only so that the conversion
+// kernels above stay as they are.  One thread per pixel quad of a row (frame width is even for alpha).
+__global__ __launch_bounds__(kRgbaBlock) void k_rgba_alpha(const uint8_t* __restrict__ slots, const int32_t* __restrict__ slot_ids,
+                                                           uint8_t* __restrict__ rgba, RgbaGeom G, int cover_w, int cover_h)
+{
+    const int x = (blockIdx.x * blockDim.x + threadIdx.x) * 2;
+    const int yy = blockIdx.y;
+    const int f = blockIdx.z;
+    if (x >= cover_w || yy >= cover_h) return;
+    const size_t stride = ((size_t)G.slot_stride_hi << 32) | G.slot_stride_lo;
+    const size_t ysz = (size_t)G.cw * G.ch;
+    const uint8_t* A = slots + (size_t)slot_ids[f] * stride + ysz + (ysz >> 1);
+    uint8_t* dst = rgba + ((size_t)f * G.fw * G.fh + (size_t)yy * G.fw + x) * 4;
+    dst[3] = A[(size_t)yy * G.cw + x];
+    if (x + 1 < cover_w) dst[7] = A[(size_t)yy * G.cw + x + 1];
 }
 
 // fills what the quad loop never writes (odd last row / column, drift leftovers) with 255

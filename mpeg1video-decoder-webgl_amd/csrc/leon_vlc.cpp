@@ -202,10 +202,10 @@ struct SliceJob { int code; size_t bitpos; };
 // What one slice contributed to one macroblock row: four entry streams (upper and lower luma block
 // row, Cb, Cr), each already ordered by group because a slice walks its macroblocks left to right,
 // plus the entry count per group.  No sort is needed afterwards -- the streams are concatenated.
-struct RowRun {
+struct RowRun {                             // streams: 0/1 luma block rows, 2 Cb, 3 Cr, 4/5 the A plane's block rows (yuva)
     int mb_row = 0;
-    std::vector<uint32_t> ent[4];
-    std::vector<uint32_t> cnt[4];
+    std::vector<uint32_t> ent[6];
+    std::vector<uint32_t> cnt[6];
 };
 struct alignas(128) SliceOut {             // one per slice; written by exactly one worker
     std::vector<RowRun> runs;
@@ -228,6 +228,7 @@ struct leon_vlc_stream {
     int type = 0;
     int full_pel_fwd = 0, fwd_rsize = 0, fwd_f = 1, full_pel_bwd = 0, bwd_rsize = 0, bwd_f = 1;
     int mbw = 0, mbh = 0, mbsize = 0, gy = 0, gc = 0, n_y = 0, n_c = 0;
+    int n_streams = 4;                          // 6 for a yuva stream (container flag `a`)
     std::vector<uint8_t> qscale, intra, repadd, mb_dir;
     std::vector<int16_t> mv_fwd, mv_bwd;
     std::vector<uint32_t> grp_off, entries, cursor;
@@ -278,7 +279,7 @@ struct SliceCtx {
     int mb_addr = 0, mb_row = 0, mb_col = 0;
     bool slice_begin = true;
     int fw_h = 0, fw_v = 0, fw_h_prev = 0, fw_v_prev = 0, bw_h = 0, bw_v = 0, bw_h_prev = 0, bw_v_prev = 0, prev_dir = 0;
-    int dc_y = 128, dc_cr = 128, dc_cb = 128, qs = 0;
+    int dc_y = 128, dc_cr = 128, dc_cb = 128, dc_a = 128, qs = 0;
     int mb_intra = 0, mot_fw = 0, mot_bw = 0;
     const char* err = nullptr;
 };
@@ -327,9 +328,10 @@ bool decode_block(SliceCtx& c, int block)
     // stream of the current row run and group inside the row
     int stream;
     uint32_t grow, bq;
-    if (block < 4) {
-        const int qb = c.mb_col * 2 + (block & 1);
-        stream = block >> 1;
+    if (block < 4 || block >= 6) {                           // luma, or the A component (blocks 6..9, placed like luma)
+        const int lb = block < 4 ? block : block - 6;
+        const int qb = c.mb_col * 2 + (lb & 1);
+        stream = (lb >> 1) + (block < 4 ? 0 : 4);
         grow = (uint32_t)(qb >> 3);
         bq = (uint32_t)(qb & 7);
     } else {
@@ -342,6 +344,7 @@ bool decode_block(SliceCtx& c, int block)
     if (c.mb_intra) {
         int predictor, size;
         if (block < 4) { predictor = c.dc_y; size = r.vlc(T.dc_lum); }
+        else if (block >= 6) { predictor = c.dc_a; size = r.vlc(T.dc_lum); }
         else { predictor = block == 4 ? c.dc_cr : c.dc_cb; size = r.vlc(T.dc_chr); }
         int dc = predictor;
         if (size > 0) {
@@ -349,7 +352,7 @@ bool decode_block(SliceCtx& c, int block)
             dc = (differential & (1 << (size - 1))) ? predictor + differential
                                                     : predictor + ((int)(0xffffffffu << size) | (differential + 1));
         }
-        if (block < 4) c.dc_y = dc; else if (block == 4) c.dc_cr = dc; else c.dc_cb = dc;
+        if (block < 4) c.dc_y = dc; else if (block >= 6) c.dc_a = dc; else if (block == 4) c.dc_cr = dc; else c.dc_cb = dc;
         c_dc_pending = dc;
         n = 1;
     }
@@ -429,7 +432,7 @@ int decode_macroblock(SliceCtx& c)
     } else {
         if (c.mb_addr + increment >= s->mbsize) return 2;
         if (increment > 1) {
-            c.dc_y = c.dc_cr = c.dc_cb = 128;
+            c.dc_y = c.dc_cr = c.dc_cb = c.dc_a = 128;
             if (type == 2) { c.fw_h = c.fw_h_prev = 0; c.fw_v = c.fw_v_prev = 0; }
         }
         while (increment > 1) {                                    // skipped macroblocks
@@ -454,9 +457,9 @@ int decode_macroblock(SliceCtx& c)
         if (so.used == so.runs.size()) so.runs.emplace_back();
         c.run = &so.runs[so.used++];
         c.run->mb_row = c.mb_row;
-        for (int k = 0; k < 4; k++) {
+        for (int k = 0; k < s->n_streams; k++) {
             c.run->ent[k].clear();
-            c.run->cnt[k].assign((size_t)(k < 2 ? s->gy : s->gc), 0u);
+            c.run->cnt[k].assign((size_t)(k == 2 || k == 3 ? s->gc : s->gy), 0u);
         }
     }
     const int mb_type = r.vlc(T.mbtype[type]);
@@ -473,7 +476,7 @@ int decode_macroblock(SliceCtx& c)
         c.prev_dir = 0;
         if (type != 1) s->repadd[mb] = 255;                        // jsv.js:1502-1505
     } else {
-        c.dc_y = c.dc_cr = c.dc_cb = 128;
+        c.dc_y = c.dc_cr = c.dc_cb = c.dc_a = 128;
         decode_motion_vectors(c);
         if (r.bad) { c.err = "invalid motion code"; return 0; }
         s->mv_fwd[2 * mb] = (int16_t)c.fw_h;
@@ -488,8 +491,14 @@ int decode_macroblock(SliceCtx& c)
     int cbp = 0;
     if (mb_type & 0x02) { cbp = r.vlc(T.cbp); if (r.bad) { c.err = "invalid coded block pattern"; return 0; } }
     else if (c.mb_intra) cbp = 0x3f;
+    // yuva (the repo's syntax, tools/jsv_writer.py write_picture): four A blocks after Cr -- all of them in an intra
+    // macroblock, else those of a 4-bit alpha_pattern that every non-intra macroblock carries here
+    int apat = 0;
+    if (s->n_streams == 6) apat = c.mb_intra ? 0xf : (int)r.get(4);
     for (int block = 0, mask = 0x20; block < 6; block++, mask >>= 1)
         if (cbp & mask) { if (!decode_block(c, block)) return 0; }
+    for (int block = 6, mask = 0x8; block < 10; block++, mask >>= 1)
+        if (apat & mask) { if (!decode_block(c, block)) return 0; }
     return 1;
 }
 
@@ -572,7 +581,8 @@ void init_buffers(leon_vlc_stream* s)        // decoders/jsv.js:355-423
     s->n_c = s->mbh * s->gc;
     I.groups_y = s->gy;
     I.groups_c = s->gc;
-    I.n_groups = s->n_y + 2 * s->n_c;
+    s->n_streams = I.has_alpha == 1 ? 6 : 4;
+    I.n_groups = s->n_y + 2 * s->n_c + (s->n_streams == 6 ? s->n_y : 0);
     s->qscale.assign((size_t)s->mbsize, 0);
     s->intra.assign((size_t)s->mbsize, 0);
     s->sequence_started = true;
@@ -686,13 +696,14 @@ int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
     const size_t ng = (size_t)s->info.n_groups;
     s->grp_off.assign(ng + 1, 0);
     auto base_of = [&](const RowRun& rr, int k) -> size_t {
+        if (k >= 4) return (size_t)s->n_y + 2 * (size_t)s->n_c + (size_t)(2 * rr.mb_row + k - 4) * (size_t)s->gy;
         return k < 2 ? (size_t)(2 * rr.mb_row + k) * (size_t)s->gy
                      : (size_t)s->n_y + (k == 3 ? (size_t)s->n_c : 0) + (size_t)rr.mb_row * (size_t)s->gc;
     };
     for (size_t j = 0; j < s->jobs.size(); j++)
         for (size_t u = 0; u < s->slice_out[j].used; u++) {
             const RowRun& rr = s->slice_out[j].runs[u];
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < s->n_streams; k++) {
                 const size_t base = base_of(rr, k);
                 for (size_t g = 0; g < rr.cnt[k].size(); g++) s->grp_off[base + g + 1] += rr.cnt[k][g];
             }
@@ -703,7 +714,7 @@ int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
     for (size_t j = 0; j < s->jobs.size(); j++)
         for (size_t u = 0; u < s->slice_out[j].used; u++) {
             const RowRun& rr = s->slice_out[j].runs[u];
-            for (int k = 0; k < 4; k++) {
+            for (int k = 0; k < s->n_streams; k++) {
                 const size_t base = base_of(rr, k);
                 const uint32_t* src = rr.ent[k].data();
                 for (size_t g = 0; g < rr.cnt[k].size(); g++) {
@@ -1006,7 +1017,7 @@ int leon_vlc_densify(const leon_vlc_info* I, const leon_vlc_picture* p, int16_t*
     memset(cb, 0, sizeof(int16_t) * (size_t)(cw >> 1) * (ch >> 1));
     memset(cr, 0, sizeof(int16_t) * (size_t)(cw >> 1) * (ch >> 1));
     const int n_y = 2 * I->mb_height * I->groups_y, n_c = I->mb_height * I->groups_c;
-    for (int g = 0; g < p->n_groups; g++) {
+    for (int g = 0; g < p->n_groups && g < n_y + 2 * n_c; g++) {      // a yuva picture's A groups: leon_vlc_densify_alpha
         int16_t* plane;
         int stride, R, gg, bw;
         if (g < n_y) { plane = y; stride = cw; R = g / I->groups_y; gg = g % I->groups_y; bw = cw >> 3; }
@@ -1021,6 +1032,26 @@ int leon_vlc_densify(const leon_vlc_info* I, const leon_vlc_picture* p, int16_t*
             const int q = gg * 8 + b;
             if (q >= bw) return fail(LEON_VLC_ERR_INVALID, "entry outside the plane");
             plane[(size_t)(R * 8 + r) * stride + q * 8 + c] = (int16_t)(v & 0xffffu);
+        }
+    }
+    return LEON_VLC_OK;
+}
+
+int leon_vlc_densify_alpha(const leon_vlc_info* I, const leon_vlc_picture* p, int16_t* a)
+{
+    if (!I || !p || !a) return fail(LEON_VLC_ERR_INVALID, "null argument");
+    const int cw = I->coded_width, ch = I->coded_height;
+    const int n_y = 2 * I->mb_height * I->groups_y, n_c = I->mb_height * I->groups_c;
+    if (p->n_groups != 2 * n_y + 2 * n_c) return fail(LEON_VLC_ERR_INVALID, "not a yuva picture");
+    memset(a, 0, sizeof(int16_t) * (size_t)cw * ch);
+    for (int g = n_y + 2 * n_c; g < p->n_groups; g++) {
+        const int k = g - n_y - 2 * n_c, R = k / I->groups_y, gg = k % I->groups_y;
+        for (uint32_t e = p->grp_off[g]; e < p->grp_off[g + 1]; e++) {
+            const uint32_t v = p->entries[e], off = (v >> 16) & 1023u;
+            const int r = (int)(off >> 7), b = (int)((off >> 4) & 7), c = (int)((off >> 1) & 7);
+            const int q = gg * 8 + b;
+            if (q >= (cw >> 3)) return fail(LEON_VLC_ERR_INVALID, "entry outside the plane");
+            a[(size_t)(R * 8 + r) * cw + q * 8 + c] = (int16_t)(v & 0xffffu);
         }
     }
     return LEON_VLC_OK;

@@ -42,14 +42,14 @@ function main() {
     const p = { type: f.type, ts: f.ts, temporalReference: f.temporalReference };
     if (!gpu) {
       const t = f.tensors;
-      p.sha = { coefY: sha(t.coefY), coefCb: sha(t.coefCb), coefCr: sha(t.coefCr), qscale: sha(t.qscale), intra: sha(t.intra),
+      p.sha = { coefY: sha(t.coefY), coefCb: sha(t.coefCb), coefCr: sha(t.coefCr), coefA: sha(t.coefA), qscale: sha(t.qscale), intra: sha(t.intra),
         repadd: sha(t.repadd), mvFwd: sha(t.mvFwd), mvBwd: sha(t.mvBwd), mbDir: sha(t.mbDir) };
       p.qscale = b64(t.qscale); p.intra = b64(t.intra); p.repadd = b64(t.repadd);
       p.mvFwd = b64(t.mvFwd); p.mvBwd = b64(t.mvBwd); p.mbDir = b64(t.mbDir);
     } else {
       const planes = dec.readPlanes(f);
       p.slot = f.slot;
-      p.planes = { y: sha(planes.y), cb: sha(planes.cb), cr: sha(planes.cr) };
+      p.planes = { y: sha(planes.y), cb: sha(planes.cb), cr: sha(planes.cr), a: sha(planes.a) };
       if (rest.includes('--rgba')) p.rgba = sha(dec.renderFrame(f, 0));
       dec.releaseFrame(f);                 // = renderFrameGL clearing texture.inuse
     }

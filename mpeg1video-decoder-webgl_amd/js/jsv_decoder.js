@@ -102,6 +102,9 @@ class JsvDecoder extends EventEmitter {
     const meta = { w: r.get(16), h: r.get(16) };
     meta.d = r.get(16) / 100;
     if (!meta.d) { meta.a = r.get(1); meta.d = r.get(23) / 100; }
+    // yuva (decoders/jsv.js:256-259: the flag makes the reference allocate four planes per slot, :59-73; it
+    // decodes three, :1223).  Here the fourth component is decoded: see decodeMacroblock.
+    this.yuva = meta.a === 1;
     this._meta = meta;
     this.emit('meta', meta);
     if (r.peek(24) === 0x000001 && r.b[(r.pos >> 3) + 3] === 0xC4) {
@@ -181,12 +184,13 @@ class JsvDecoder extends EventEmitter {
     this.currentYDCT16 = new Int16Array(this.codedSize);
     this.currentCbDCT16 = new Int16Array(this.codedSize >> 2);
     this.currentCrDCT16 = new Int16Array(this.codedSize >> 2);
+    this.currentADCT16 = this.yuva ? new Int16Array(this.codedSize) : null;
     this.sequenceStarted = true;
     if (this.backendFactory) {
       // = decoder._initGL(gl) + initGLBuffers (player/easybits.player.js:584-585, jsv.js:51-87)
       this.backend = this.backendFactory.create({
         codedWidth: this.codedWidth, codedHeight: this.codedHeight, frameWidth: this.frameWidth,
-        frameHeight: this.frameHeight, nSlots: this.rendered_frames_n, deviceId: this.deviceId });
+        frameHeight: this.frameHeight, nSlots: this.rendered_frames_n, deviceId: this.deviceId, alpha: this.yuva ? 1 : 0 });
     }
   }
 
@@ -232,6 +236,7 @@ class JsvDecoder extends EventEmitter {
       this.currentYDCT16 = new Int16Array(this.codedSize);
       this.currentCbDCT16 = new Int16Array(this.codedSize >> 2);
       this.currentCrDCT16 = new Int16Array(this.codedSize >> 2);
+      if (this.yuva) this.currentADCT16 = new Int16Array(this.codedSize);
     }
     void previous;
     let code;
@@ -258,6 +263,7 @@ class JsvDecoder extends EventEmitter {
     this.dcPredictorY = 128;
     this.dcPredictorCr = 128;
     this.dcPredictorCb = 128;
+    this.dcPredictorA = 128;
     this.quantizerScale = r.get(5);
     while (r.get(1)) r.skip(8);
     do { this.decodeMacroblock(); } while (!r.nextBitsAreStartCode());
@@ -276,7 +282,7 @@ class JsvDecoder extends EventEmitter {
     } else {
       if (this.macroblockAddress + increment >= this.mbSize) return;
       if (increment > 1) {
-        this.dcPredictorY = this.dcPredictorCr = this.dcPredictorCb = 128;
+        this.dcPredictorY = this.dcPredictorCr = this.dcPredictorCb = this.dcPredictorA = 128;
         if (type === PICTURE_TYPE_P) {
           this.motionFwH = this.motionFwHPrev = 0;
           this.motionFwV = this.motionFwVPrev = 0;
@@ -313,7 +319,7 @@ class JsvDecoder extends EventEmitter {
       this.prevDir = 0;
       if (type !== PICTURE_TYPE_I) this.macroblockRepAdd[mb] = 255;     // jsv.js:1502-1505
     } else {
-      this.dcPredictorY = this.dcPredictorCr = this.dcPredictorCb = 128;
+      this.dcPredictorY = this.dcPredictorCr = this.dcPredictorCb = this.dcPredictorA = 128;
       this.decodeMotionVectors();
       this.macroblockMV[2 * mb] = this.motionFwH;
       this.macroblockMV[2 * mb + 1] = this.motionFwV;
@@ -325,8 +331,15 @@ class JsvDecoder extends EventEmitter {
       }
     }
     const cbp = (mbType & 0x02) ? r.vlc(T.CBP) : (this.macroblockIntra ? 0x3f : 0);
+    // yuva (this repo's syntax, tools/jsv_writer.py write_picture -- the reference's slice loop reads six blocks,
+    // jsv.js:817-828): four A blocks after Cr, all of them in an intra macroblock, else those named by a 4-bit
+    // alpha_pattern that every non-intra macroblock carries at this point
+    const apat = this.yuva ? (this.macroblockIntra ? 0xf : r.get(4)) : 0;
     for (let block = 0, mask = 0x20; block < 6; block++, mask >>= 1) {
       if (cbp & mask) this.decodeBlock(block);
+    }
+    for (let block = 6, mask = 0x8; block < 10; block++, mask >>= 1) {
+      if (apat & mask) this.decodeBlock(block);
     }
   }
 
@@ -367,9 +380,10 @@ class JsvDecoder extends EventEmitter {
   decodeBlock(block) {
     const r = this.buffer;
     let plane, stride, base, n = 0;
-    if (block < 4) {
-      plane = this.currentYDCT16; stride = this.codedWidth;
-      base = (this.mbRow * 16 + ((block >> 1) << 3)) * stride + this.mbCol * 16 + ((block & 1) << 3);
+    if (block < 4 || block >= 6) {                       // luma, or the A component (blocks 6..9, placed like luma)
+      const lb = block < 4 ? block : block - 6;
+      plane = block < 4 ? this.currentYDCT16 : this.currentADCT16; stride = this.codedWidth;
+      base = (this.mbRow * 16 + ((lb >> 1) << 3)) * stride + this.mbCol * 16 + ((lb & 1) << 3);
     } else {
       plane = block === 4 ? this.currentCbDCT16 : this.currentCrDCT16; stride = this.halfWidth;
       base = this.mbRow * 8 * stride + this.mbCol * 8;
@@ -380,13 +394,15 @@ class JsvDecoder extends EventEmitter {
     if (this.macroblockIntra) {
       let predictor, size;
       if (block < 4) { predictor = this.dcPredictorY; size = r.vlc(T.DC_LUM); }
+      else if (block >= 6) { predictor = this.dcPredictorA; size = r.vlc(T.DC_LUM); }
       else { predictor = block === 4 ? this.dcPredictorCr : this.dcPredictorCb; size = r.vlc(T.DC_CHR); }
       let dc = predictor;
       if (size > 0) {
         const differential = r.get(size);
         dc = (differential & (1 << (size - 1))) ? predictor + differential : predictor + ((-1 << size) | (differential + 1));
       }
-      if (block < 4) this.dcPredictorY = dc; else if (block === 4) this.dcPredictorCr = dc; else this.dcPredictorCb = dc;
+      if (block < 4) this.dcPredictorY = dc; else if (block >= 6) this.dcPredictorA = dc;
+      else if (block === 4) this.dcPredictorCr = dc; else this.dcPredictorCb = dc;
       plane[base] = dc;
       n = 1;
     }
@@ -446,7 +462,7 @@ class JsvDecoder extends EventEmitter {
   _boundary(type) {
     return {
       type,
-      coefY: this.currentYDCT16, coefCb: this.currentCbDCT16, coefCr: this.currentCrDCT16,
+      coefY: this.currentYDCT16, coefCb: this.currentCbDCT16, coefCr: this.currentCrDCT16, coefA: this.currentADCT16,
       qscale: this.macroblockQuant, intra: this.macroblockIsIntra,
       repadd: type !== PICTURE_TYPE_I ? this.macroblockRepAdd : null,
       mvFwd: type !== PICTURE_TYPE_I ? this.macroblockMV : null,
@@ -459,7 +475,7 @@ class JsvDecoder extends EventEmitter {
 
   _snapshot(pic) {
     const c = (a) => (a ? a.slice() : null);
-    return { type: pic.type, coefY: c(pic.coefY), coefCb: c(pic.coefCb), coefCr: c(pic.coefCr), qscale: c(pic.qscale),
+    return { type: pic.type, coefY: c(pic.coefY), coefCb: c(pic.coefCb), coefCr: c(pic.coefCr), coefA: c(pic.coefA), qscale: c(pic.qscale),
       intra: c(pic.intra), repadd: c(pic.repadd), mvFwd: c(pic.mvFwd), mvBwd: c(pic.mvBwd), mbDir: c(pic.mbDir) };
   }
 

@@ -24,9 +24,11 @@ function densify(info, pic) {
   const cw = info.codedWidth, ch = info.codedHeight, hw = cw >> 1;
   const y = new Int16Array(cw * ch), cb = new Int16Array((cw * ch) >> 2), cr = new Int16Array((cw * ch) >> 2);
   const nY = 2 * info.mbHeight * info.groupsY, nC = info.mbHeight * info.groupsC;
+  const a = info.nGroups > nY + 2 * nC ? new Int16Array(cw * ch) : null;       // yuva: the A groups follow Cr's
   for (let g = 0; g < info.nGroups; g++) {
     let plane, stride, R, gg;
     if (g < nY) { plane = y; stride = cw; R = (g / info.groupsY) | 0; gg = g % info.groupsY; }
+    else if (g >= nY + 2 * nC) { const k = g - nY - 2 * nC; plane = a; stride = cw; R = (k / info.groupsY) | 0; gg = k % info.groupsY; }
     else { const k = (g - nY) % nC; plane = g - nY < nC ? cb : cr; stride = hw; R = (k / info.groupsC) | 0; gg = k % info.groupsC; }
     for (let e = pic.grpOff[g]; e < pic.grpOff[g + 1]; e++) {
       const v = pic.entries[e], off = (v >>> 16) & 1023;
@@ -34,7 +36,7 @@ function densify(info, pic) {
       plane[(R * 8 + r) * stride + (gg * 8 + b) * 8 + c] = (v << 16) >> 16;
     }
   }
-  return { coefY: y, coefCb: cb, coefCr: cr };
+  return { coefY: y, coefCb: cb, coefCr: cr, coefA: a };
 }
 
 class NativeJsvDecoder extends JsvDecoder {
@@ -74,7 +76,8 @@ class NativeJsvDecoder extends JsvDecoder {
       if (this.backendFactory) {
         this.backend = this.backendFactory.create({
           codedWidth: this.codedWidth, codedHeight: this.codedHeight, frameWidth: this.frameWidth,
-          frameHeight: this.frameHeight, nSlots: this.rendered_frames_n, deviceId: this.deviceId });
+          frameHeight: this.frameHeight, nSlots: this.rendered_frames_n, deviceId: this.deviceId,
+          alpha: this._meta && this._meta.a === 1 ? 1 : 0 });       // yuva: the sparse lists carry the A groups
       }
     }
     if (this.backend) this.backend.setQuantMatrices(this.intraQuantMatrix, this.nonIntraQuantMatrix);
@@ -118,7 +121,7 @@ class NativeJsvDecoder extends JsvDecoder {
   _snapshot(pic) {
     const d = densify(this.info, pic);
     const c = (a) => (a ? a.slice() : null);
-    return { type: pic.type, coefY: d.coefY, coefCb: d.coefCb, coefCr: d.coefCr, qscale: c(pic.qscale), intra: c(pic.intra),
+    return { type: pic.type, coefY: d.coefY, coefCb: d.coefCb, coefCr: d.coefCr, coefA: d.coefA, qscale: c(pic.qscale), intra: c(pic.intra),
       repadd: c(pic.repadd), mvFwd: c(pic.mvFwd), mvBwd: c(pic.mvBwd), mbDir: c(pic.mbDir),
       nEntries: pic.nEntries };
   }

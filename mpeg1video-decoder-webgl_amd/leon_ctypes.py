@@ -25,7 +25,7 @@ SYMBOLS = [
     "leon_submit_batch", "leon_batch_create", "leon_batch_run", "leon_batch_destroy",
     "leon_submit_sparse", "leon_batch_create_sparse",
     "leon_convert_rgba", "leon_convert_rgba_batch", "leon_read_planes", "leon_write_planes",
-    "leon_slot_device_ptr", "leon_sync", "leon_set_overlap_convert", "leon_timing_enable", "leon_timing_reset", "leon_timing_get",
+    "leon_read_alpha_plane", "leon_write_alpha_plane", "leon_slot_device_ptr", "leon_sync", "leon_set_overlap_convert", "leon_timing_enable", "leon_timing_reset", "leon_timing_get",
     "leon_measure_copy_bandwidth",
 ]
 # include/leon_pipeline.h (same library)
@@ -44,7 +44,7 @@ class LeonError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("coded_width", C.c_int32), ("coded_height", C.c_int32), ("frame_width", C.c_int32),
                 ("frame_height", C.c_int32), ("n_slots", C.c_int32), ("device_id", C.c_int32),
-                ("stream", C.c_void_p)]
+                ("stream", C.c_void_p), ("alpha", C.c_int32), ("reserved", C.c_int32)]
 
 
 class Picture(C.Structure):
@@ -54,7 +54,8 @@ class Picture(C.Structure):
                 ("repadd", C.c_void_p), ("mv_fwd", C.c_void_p), ("mv_bwd", C.c_void_p),
                 ("mb_dir", C.c_void_p),
                 # ABI 2: fused display conversion (device pointer to the RGBA frame, or NULL)
-                ("rgba_out", C.c_void_p), ("no_planes", C.c_int32), ("reserved", C.c_int32)]
+                ("rgba_out", C.c_void_p), ("no_planes", C.c_int32), ("reserved", C.c_int32),
+                ("coef_a", C.c_void_p)]
 
 
 class SparsePicture(C.Structure):
@@ -133,6 +134,8 @@ def load():
     lib.leon_convert_rgba_batch.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
     lib.leon_read_planes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.leon_write_planes.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.leon_read_alpha_plane.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+    lib.leon_write_alpha_plane.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
     lib.leon_slot_device_ptr.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]
     lib.leon_sync.argtypes = [C.c_void_p]
     lib.leon_set_overlap_convert.argtypes = [C.c_void_p, C.c_int32]
@@ -169,9 +172,10 @@ def _hostptr(a, dtype, keep):
 
 def make_picture(ptype, out_slot, coef_y, coef_cb, coef_cr, qscale, intra, repadd=None, mv_fwd=None,
                  mv_bwd=None, mb_dir=None, ref_fwd_slot=-1, ref_bwd_slot=-1, keep=None, device=False,
-                 rgba_out=None, no_planes=False):
+                 rgba_out=None, no_planes=False, coef_a=None):
     """Fill a Picture from numpy arrays (host) or raw device addresses (device=True: ints).
-    rgba_out: device address of the RGBA frame for the fused display conversion (always a device address)."""
+    rgba_out: device address of the RGBA frame for the fused display conversion (always a device address);
+    coef_a: the A plane's levels for a yuva decoder."""
     p = Picture()
     p.type, p.out_slot, p.ref_fwd_slot, p.ref_bwd_slot = ptype, out_slot, ref_fwd_slot, ref_bwd_slot
     p.rgba_out = None if rgba_out is None else int(rgba_out)
@@ -180,8 +184,10 @@ def make_picture(ptype, out_slot, coef_y, coef_cb, coef_cr, qscale, intra, repad
         vals = (coef_y, coef_cb, coef_cr, qscale, intra, repadd, mv_fwd, mv_bwd, mb_dir)
         (p.coef_y, p.coef_cb, p.coef_cr, p.qscale, p.intra, p.repadd, p.mv_fwd, p.mv_bwd, p.mb_dir) = \
             [None if v is None else int(v) for v in vals]
+        p.coef_a = None if coef_a is None else int(coef_a)
         return p
     keep = keep if keep is not None else []
+    p.coef_a = _hostptr(coef_a, np.int16, keep)
     p.coef_y = _hostptr(coef_y, np.int16, keep)
     p.coef_cb = _hostptr(coef_cb, np.int16, keep)
     p.coef_cr = _hostptr(coef_cr, np.int16, keep)
@@ -225,9 +231,9 @@ def make_sparse_picture(ptype, out_slot, grp_off, entries, n_entries, qscale, in
 class Decoder:
     """Thin object wrapper over the C ABI; method names follow include/leon.h."""
 
-    def __init__(self, coded_w, coded_h, frame_w=None, frame_h=None, n_slots=13, device_id=0, stream=None):
+    def __init__(self, coded_w, coded_h, frame_w=None, frame_h=None, n_slots=13, device_id=0, stream=None, alpha=False):
         self.lib = load()
-        cfg = Config(coded_w, coded_h, frame_w or coded_w, frame_h or coded_h, n_slots, device_id, stream)
+        cfg = Config(coded_w, coded_h, frame_w or coded_w, frame_h or coded_h, n_slots, device_id, stream, 1 if alpha else 0, 0)
         h = C.c_void_p()
         _chk(self.lib.leon_create(C.byref(cfg), C.byref(h)))
         self.h = h
@@ -306,6 +312,15 @@ class Decoder:
         cr = np.empty((self.ch // 2, self.cw // 2), dtype=np.uint8)
         _chk(self.lib.leon_read_planes(self.h, slot, y.ctypes.data, cb.ctypes.data, cr.ctypes.data))
         return y, cb, cr
+
+    def read_alpha_plane(self, slot):
+        a = np.empty((self.ch, self.cw), dtype=np.uint8)
+        _chk(self.lib.leon_read_alpha_plane(self.h, slot, a.ctypes.data))
+        return a
+
+    def write_alpha_plane(self, slot, a):
+        keep = []
+        _chk(self.lib.leon_write_alpha_plane(self.h, slot, _hostptr(a, np.uint8, keep)))
 
     def write_planes(self, slot, y, cb, cr):
         keep = []

@@ -8,7 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SYMBOLS = ["leon_vlc_last_error", "leon_vlc_open", "leon_vlc_close", "leon_vlc_get_info",
-           "leon_vlc_next_picture", "leon_vlc_seek", "leon_vlc_densify", "leon_vlc_get_keymap"]
+           "leon_vlc_next_picture", "leon_vlc_seek", "leon_vlc_densify", "leon_vlc_densify_alpha", "leon_vlc_get_keymap"]
 
 
 class Info(C.Structure):
@@ -45,6 +45,7 @@ def load():
     lib.leon_vlc_close.restype = None
     lib.leon_vlc_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
     lib.leon_vlc_next_picture.argtypes = [C.c_void_p, C.POINTER(Picture)]
+    lib.leon_vlc_densify_alpha.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
     lib.leon_vlc_get_keymap.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
     lib.leon_vlc_seek.argtypes = [C.c_void_p, C.c_double, C.POINTER(C.c_uint64)]
     lib.leon_vlc_densify.argtypes = [C.POINTER(Info), C.POINTER(Picture), C.c_void_p, C.c_void_p, C.c_void_p]
@@ -114,6 +115,11 @@ class Stream:
             if self.lib.leon_vlc_densify(C.byref(I), C.byref(p), y.ctypes.data, cb.ctypes.data, cr.ctypes.data) != 0:
                 raise VlcError(self.lib.leon_vlc_last_error().decode())
             out["coef_y"], out["coef_cb"], out["coef_cr"] = y, cb, cr
+            if I.has_alpha == 1:
+                a = np.empty(cw * ch, np.int16)
+                if self.lib.leon_vlc_densify_alpha(C.byref(I), C.byref(p), a.ctypes.data) != 0:
+                    raise VlcError(self.lib.leon_vlc_last_error().decode())
+                out["coef_a"] = a
         return out
 
     def keymap(self):
@@ -130,14 +136,17 @@ class Stream:
         return int(off.value)
 
 
-def sparsify(coef_y, coef_cb, coef_cr, cw, ch):
+def sparsify(coef_y, coef_cb, coef_cr, cw, ch, coef_a=None):
     """Dense int16 planes -> (grp_off, entries) in the format of include/leon_vlc.h (numpy; tests
-    and synthetic workloads)."""
+    and synthetic workloads).  coef_a: the A plane of a yuva picture; its groups follow the Cr groups."""
     mbw, mbh = cw // 16, ch // 16
     gy, gc = (2 * mbw + 7) // 8, (mbw + 7) // 8
     gids, ents = [], []
     base = 0
-    for plane, W, H, G in ((coef_y, cw, ch, gy), (coef_cb, cw // 2, ch // 2, gc), (coef_cr, cw // 2, ch // 2, gc)):
+    planes = [(coef_y, cw, ch, gy), (coef_cb, cw // 2, ch // 2, gc), (coef_cr, cw // 2, ch // 2, gc)]
+    if coef_a is not None:
+        planes.append((coef_a, cw, ch, gy))
+    for plane, W, H, G in planes:
         p = np.asarray(plane, dtype=np.int16).reshape(H, W)
         ys, xs = np.nonzero(p)
         R, r = ys >> 3, ys & 7

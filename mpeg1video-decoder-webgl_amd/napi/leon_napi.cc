@@ -180,6 +180,7 @@ napi_value SubmitPicture(napi_env env, napi_callback_info info)
               get_array(env, p, "coefY", napi_int16_array, ny, (const void**)&pic.coef_y) &&
               get_array(env, p, "coefCb", napi_int16_array, nc, (const void**)&pic.coef_cb) &&
               get_array(env, p, "coefCr", napi_int16_array, nc, (const void**)&pic.coef_cr) &&
+              get_array(env, p, "coefA", napi_int16_array, ny, (const void**)&pic.coef_a) &&
               get_array(env, p, "qscale", napi_uint8_array, mbs, (const void**)&pic.qscale) &&
               get_array(env, p, "intra", napi_uint8_array, mbs, (const void**)&pic.intra) &&
               get_array(env, p, "repadd", napi_uint8_array, mbs, (const void**)&pic.repadd) &&
@@ -211,7 +212,7 @@ napi_value SubmitSparse(napi_env env, napi_callback_info info)
     memset(&pic, 0, sizeof pic);
     const int mbw = h->cfg.coded_width / 16, mbh = h->cfg.coded_height / 16;
     const size_t mbs = (size_t)mbw * mbh;
-    const size_t n_groups = (size_t)2 * mbh * ((2 * mbw + 7) / 8) + (size_t)2 * mbh * ((mbw + 7) / 8);
+    const size_t n_groups = (size_t)2 * mbh * ((2 * mbw + 7) / 8) * (h->cfg.alpha ? 2 : 1) + (size_t)2 * mbh * ((mbw + 7) / 8);
     int32_t n_entries = 0;
     bool ok = get_i32(env, p, "type", &pic.type, 0) && get_i32(env, p, "outSlot", &pic.out_slot, -1) &&
               get_i32(env, p, "refFwdSlot", &pic.ref_fwd_slot, -1) && get_i32(env, p, "refBwdSlot", &pic.ref_bwd_slot, -1) &&
@@ -282,6 +283,14 @@ napi_value ReadPlanes(napi_env env, napi_callback_info info)
     napi_set_named_property(env, o, "y", ty);
     napi_set_named_property(env, o, "cb", tcb);
     napi_set_named_property(env, o, "cr", tcr);
+    if (h->cfg.alpha) {                       // yuva: the fourth plane of the slot
+        uint8_t* a;
+        napi_value ta = make_u8(env, ny, &a);
+        if (!ta) return nullptr;
+        rc = leon_read_alpha_plane(h->d, slot, a);
+        if (rc != LEON_OK) return throw_leon(env, rc);
+        napi_set_named_property(env, o, "a", ta);
+    }
     return o;
 }
 
@@ -321,7 +330,8 @@ napi_value Create(napi_env env, napi_callback_info info)
     h->d = nullptr;
     bool ok = get_i32(env, argv[0], "codedWidth", &h->cfg.coded_width, 0) && get_i32(env, argv[0], "codedHeight", &h->cfg.coded_height, 0) &&
               get_i32(env, argv[0], "frameWidth", &h->cfg.frame_width, 0) && get_i32(env, argv[0], "frameHeight", &h->cfg.frame_height, 0) &&
-              get_i32(env, argv[0], "nSlots", &h->cfg.n_slots, 13) && get_i32(env, argv[0], "deviceId", &h->cfg.device_id, 0);
+              get_i32(env, argv[0], "nSlots", &h->cfg.n_slots, 13) && get_i32(env, argv[0], "deviceId", &h->cfg.device_id, 0) &&
+              get_i32(env, argv[0], "alpha", &h->cfg.alpha, 0);
     if (!ok) {
         delete h;
         napi_throw_type_error(env, nullptr, "create: integer fields expected");

@@ -98,8 +98,9 @@ def _vectors(rng, mbw, mbh, mv_range, coherent):
 
 def make_picture(rng, cw, ch, ptype, mv_range=31, in_picture=True, qm_intra=DEFAULT_INTRA_QUANT,
                  qm_non=DEFAULT_NON_INTRA_QUANT, intra_frac=0.10, skip_frac=0.15, uncoded_frac=0.3,
-                 force_dir=None, mv_coherent=1):
-    """Boundary tensors of one picture.  Returns a dict of numpy arrays."""
+                 force_dir=None, mv_coherent=1, alpha=False):
+    """Boundary tensors of one picture.  Returns a dict of numpy arrays.
+    alpha: a fourth, luma-sized component ("coef_a") for yuva streams (container flag `a`, decoders/jsv.js:256-259)."""
     mbw, mbh = cw // 16, ch // 16
     nmb = mbw * mbh
     qscale = ((np.arange(mbh)[:, None] % 30) + 2 + np.zeros((1, mbw), dtype=np.int64)).astype(np.uint8).reshape(-1)
@@ -128,9 +129,9 @@ def make_picture(rng, cw, ch, ptype, mv_range=31, in_picture=True, qm_intra=DEFA
                 t["mb_dir"][:] = force_dir
     t["intra"] = intra
     planes = []
-    for comp in range(3):
-        W, H = (cw, ch) if comp == 0 else (cw // 2, ch // 2)
-        chroma = comp != 0
+    for comp in range(4 if alpha else 3):
+        W, H = (cw, ch) if comp in (0, 3) else (cw // 2, ch // 2)
+        chroma = comp in (1, 2)
         pix = smooth_scene(rng, W, H)
         res = smooth_scene(rng, W, H, lo=-48.0, hi=48.0, noise=6.0)
         ia_px = np.kron(_mb_to_blocks(intra, mbw, mbh, chroma), np.ones((8, 8), dtype=np.uint8)).astype(bool)
@@ -143,7 +144,9 @@ def make_picture(rng, cw, ch, ptype, mv_range=31, in_picture=True, qm_intra=DEFA
             unc &= ~_mb_to_blocks(intra, mbw, mbh, chroma).astype(bool)
             lv[unc] = 0
         planes.append(np.ascontiguousarray(blocks_to_plane(lv)))
-    t["coef_y"], t["coef_cb"], t["coef_cr"] = planes
+    t["coef_y"], t["coef_cb"], t["coef_cr"] = planes[:3]
+    if alpha:
+        t["coef_a"] = planes[3]
     return t
 
 

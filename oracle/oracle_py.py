@@ -82,10 +82,51 @@ def predict_plane(ref, W, H, is_chroma, mv, mbw):
     return out.reshape(H, W)
 
 
+def decode_alpha_plane(ptype, cw, ch, coef_a, qscale, intra, repadd=None, mb_dir=None, mv_fwd=None, mv_bwd=None,
+                       qm=None, pm=None, ref_fwd_a=None, ref_bwd_a=None):
+    """The fourth component of a yuva picture (container flag `a`, decoders/jsv.js:256-259; 4-plane
+    output ring :59-73): a luma-sized plane reconstructed exactly like luma -- same maps, same (luma)
+    vectors, same matrices -- from its own coefficient plane and the references' alpha planes.  The
+    reference allocates the plane and never decodes it (IDCT_GL loops over three components,
+    :1223), so this is the repo's definition, composed from the pinned per-plane functions."""
+    qm = default_qm() if qm is None else np.ascontiguousarray(qm, dtype=np.uint8)
+    pm = premultiplier() if pm is None else np.ascontiguousarray(pm, dtype=np.uint8)
+    mbw = cw // 16
+    scratch = pass1_plane(coef_a, cw, ch, False, qscale, intra, mbw, qm, pm)
+    out = np.zeros(cw * ch, dtype=np.uint8)
+    p = lambda a, dt: None if a is None else np.ascontiguousarray(a, dtype=dt)
+    sc = np.ascontiguousarray(scratch, dtype=np.int16)
+    if ptype == 1:
+        lib().lo_pass2_intra_plane(sc.ctypes.data_as(C.c_void_p), cw, ch, out.ctypes.data_as(C.c_void_p))
+        return out
+    rep, mvf = p(repadd, np.uint8), p(mv_fwd, np.int16)
+    rf = p(ref_fwd_a, np.uint8)
+    if ptype == 2:
+        lib().lo_pass2_inter_plane(sc.ctypes.data_as(C.c_void_p), cw, ch, 0, rep.ctypes.data_as(C.c_void_p),
+                                   mvf.ctypes.data_as(C.c_void_p), mbw, rf.ctypes.data_as(C.c_void_p),
+                                   out.ctypes.data_as(C.c_void_p))
+        return out
+    md, mvb, rb = p(mb_dir, np.uint8), p(mv_bwd, np.int16), p(ref_bwd_a, np.uint8)
+    lib().lo_pass2_bidir_plane(sc.ctypes.data_as(C.c_void_p), cw, ch, 0, rep.ctypes.data_as(C.c_void_p),
+                               md.ctypes.data_as(C.c_void_p), mvf.ctypes.data_as(C.c_void_p), mvb.ctypes.data_as(C.c_void_p), mbw,
+                               rf.ctypes.data_as(C.c_void_p), rb.ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p))
+    return out
+
+
 def decode_picture(ptype, cw, ch, coef_y, coef_cb, coef_cr, qscale, intra, repadd=None,
                    mb_dir=None, mv_fwd=None, mv_bwd=None, qm=None, pm=None,
-                   ref_fwd=None, ref_bwd=None):
-    """Returns the decoded picture as one uint8 array [Y | Cb | Cr] of cw*ch*3/2 bytes."""
+                   ref_fwd=None, ref_bwd=None, coef_a=None):
+    """Returns the decoded picture as one uint8 array [Y | Cb | Cr] of cw*ch*3/2 bytes -- with coef_a
+    (yuva) [Y | Cb | Cr | A] of cw*ch*5/2 bytes, the references in the same layout."""
+    if coef_a is not None:
+        n3 = cw * ch * 3 // 2
+        base = decode_picture(ptype, cw, ch, coef_y, coef_cb, coef_cr, qscale, intra, repadd=repadd, mb_dir=mb_dir,
+                              mv_fwd=mv_fwd, mv_bwd=mv_bwd, qm=qm, pm=pm,
+                              ref_fwd=None if ref_fwd is None else ref_fwd[:n3], ref_bwd=None if ref_bwd is None else ref_bwd[:n3])
+        a = decode_alpha_plane(ptype, cw, ch, coef_a, qscale, intra, repadd=repadd, mb_dir=mb_dir, mv_fwd=mv_fwd, mv_bwd=mv_bwd,
+                               qm=qm, pm=pm, ref_fwd_a=None if ref_fwd is None else ref_fwd[n3:],
+                               ref_bwd_a=None if ref_bwd is None else ref_bwd[n3:])
+        return np.concatenate([base, a])
     keep = []
 
     def ptr(a, dt):
@@ -114,7 +155,20 @@ def split_planes(buf, cw, ch):
             buf[n + n // 4:n + n // 2].reshape(ch // 2, cw // 2))
 
 
-def ycbcr_to_rgba(y, cb, cr, coded_w, frame_w, frame_h, mode="cpu"):
+def ycbcr_to_rgba(y, cb, cr, coded_w, frame_w, frame_h, mode="cpu", a=None):
+    """a: the alpha plane of a yuva picture -- the A byte of every pixel the conversion writes is the
+    plane's sample instead of 255 (pixels the CPU twin's quad loop never reaches keep fillArray's 255)"""
+    if a is not None:
+        out = ycbcr_to_rgba(y, cb, cr, coded_w, frame_w, frame_h, mode)
+        ap = np.ascontiguousarray(a, dtype=np.uint8).reshape(-1, coded_w)[:frame_h, :frame_w]
+        if mode == "cpu":       # the quad loop covers (frame_w >> 1) x (frame_h >> 1) quads (even sizes: everything)
+            w2, h2 = (frame_w >> 1) * 2, (frame_h >> 1) * 2
+            if frame_w & 1:
+                raise ValueError("alpha with an odd frame width is not defined (the CPU twin's index drift)")
+            out[:h2, :w2, 3] = ap[:h2, :w2]
+        else:
+            out[:, :, 3] = ap
+        return out
     y = np.ascontiguousarray(y, dtype=np.uint8)
     cb = np.ascontiguousarray(cb, dtype=np.uint8)
     cr = np.ascontiguousarray(cr, dtype=np.uint8)

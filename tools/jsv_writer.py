@@ -188,20 +188,34 @@ def _put_block(bw, levels_zz, intra, is_chroma, dc_pred):
 
 
 def _mb_blocks(t, mbx, mby):
-    """The six 8x8 blocks of a macroblock as zig-zag level vectors."""
+    """The six 8x8 blocks of a macroblock as zig-zag level vectors -- ten in a yuva stream: the four
+    blocks of the A component (laid out like the luma blocks) follow Cr."""
     out = []
     for b in range(4):
         y0, x0 = mby * 16 + 8 * (b >> 1), mbx * 16 + 8 * (b & 1)
         out.append(t["coef_y"][y0:y0 + 8, x0:x0 + 8].reshape(64)[ZIGZAG])
     for k in ("coef_cb", "coef_cr"):
         out.append(t[k][mby * 8:mby * 8 + 8, mbx * 8:mbx * 8 + 8].reshape(64)[ZIGZAG])
+    if "coef_a" in t:
+        for b in range(4):
+            y0, x0 = mby * 16 + 8 * (b >> 1), mbx * 16 + 8 * (b & 1)
+            out.append(t["coef_a"][y0:y0 + 8, x0:x0 + 8].reshape(64)[ZIGZAG])
     return out
 
 
 def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0), slice_mbs=None):
     """One picture.  slice_mbs None: one slice per macroblock row; else a new slice every slice_mbs
-    macroblocks in raster order (slices then start mid-row and may span rows, as MPEG-1 allows)."""
+    macroblocks in raster order (slices then start mid-row and may span rows, as MPEG-1 allows).
+
+    yuva ("coef_a" in t; container flag `a`, decoders/jsv.js:256-259).  The reference defines no syntax
+    for the fourth component (its slice loop reads six blocks, jsv.js:817-828), so this is the repo's:
+    a macroblock carries four more blocks, A0..A3, placed like the luma blocks and coded like them
+    (luminance DC table, own DC predictor, same AC codes), after Cr.  Which of them are coded:
+    all four in an intra macroblock; otherwise a 4-bit alpha_pattern (A0 = MSB) that follows
+    coded_block_pattern -- or the vectors, when the macroblock type has no pattern -- in EVERY
+    non-intra macroblock.  A macroblock is skipped only if its alpha blocks are empty too."""
     ptype = t["type"]
+    alpha = "coef_a" in t
     mbw, mbh = cw // 16, ch // 16
     bw.start_code(START_PICTURE)
     bw.put(temporal_ref & 1023, 10)
@@ -224,7 +238,7 @@ def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0), s
             qcur = 1
         bw.put(qcur, 5)
         bw.put(0, 1)                                       # extra_bit_slice
-        dc_pred = [128, 128, 128]
+        dc_pred = [128, 128, 128, 128]
         pmv_f = [0, 0]
         pmv_b = [0, 0]
         last_coded = first - (first % mbw) - 1            # the slice's address origin: row start - 1
@@ -239,12 +253,17 @@ def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0), s
                     cbp |= 1 << (5 - b)
             if intra:
                 cbp = 0x3f
+            apat = 0
+            if alpha:
+                for b in range(4):
+                    if intra or np.any(blocks[6 + b] != 0):
+                        apat |= 1 << (3 - b)
             mvf = [int(v) for v in t["mv_fwd"][2 * mb:2 * mb + 2]] if ptype != PIC_I else [0, 0]
             mvb = [int(v) for v in t["mv_bwd"][2 * mb:2 * mb + 2]] if ptype == PIC_B else [0, 0]
             d = int(t["mb_dir"][mb]) & 3 if ptype == PIC_B else 1
             # a P macroblock without coefficients and with a zero vector may be skipped, but never
             # the first or last one of a slice
-            if ptype == PIC_P and not intra and cbp == 0 and mvf == [0, 0] and first < mb < last:
+            if ptype == PIC_P and not intra and cbp == 0 and apat == 0 and mvf == [0, 0] and first < mb < last:
                 continue
             flags = 0
             if intra:
@@ -270,14 +289,14 @@ def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0), s
             elif skipped and ptype == PIC_P:
                 pmv_f = [0, 0]                             # skipped P macroblocks reset the predictor
             if skipped and mb != first:
-                dc_pred = [128, 128, 128]
+                dc_pred = [128, 128, 128, 128]
             _put_mba(bw, skipped + 1)
             bw.vlc(types[flags])
             if flags & 0x10:
                 bw.put(q, 5)
                 qcur = q
             if not intra and (prev_intra or True):
-                dc_pred = [128, 128, 128]                  # a non-intra macroblock resets the DC predictors
+                dc_pred = [128, 128, 128, 128]             # a non-intra macroblock resets the DC predictors
             if ptype == PIC_P and not intra and not (flags & 0x08):
                 pmv_f = [0, 0]                             # no-MC macroblock: vector and predictor are zero
                 assert mvf == [0, 0]
@@ -296,16 +315,21 @@ def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0), s
                     pmv_b[k] = v
             if (flags & 0x02) and not intra:
                 bw.vlc(CBP[cbp])
+            if alpha and not intra:
+                bw.put(apat, 4)
             for b in range(6):
                 if cbp & (1 << (5 - b)):
                     comp = 0 if b < 4 else b - 3
                     dc_pred[comp] = _put_block(bw, blocks[b], intra, b >= 4, dc_pred[comp])
+            for b in range(4):
+                if apat & (1 << (3 - b)):
+                    dc_pred[3] = _put_block(bw, blocks[6 + b], intra, False, dc_pred[3])
             last_coded = mb
             prev_intra = intra
 
 
 def write_stream(pictures, cw, ch, frame_w=None, frame_h=None, rate_idx=3, gop_starts=None,
-                 qm_intra=None, qm_non_intra=None, key_map=True, f_code=(2, 2), slice_mbs=None):
+                 qm_intra=None, qm_non_intra=None, key_map=True, f_code=(2, 2), slice_mbs=None, alpha=None):
     """pictures: tensors dicts in CODED order, each with 'display' (temporal reference inside
     its GOP).  gop_starts: indices into `pictures` where a sequence header + GOP header go.
     Returns bytes."""
@@ -355,7 +379,9 @@ def write_stream(pictures, cw, ch, frame_w=None, frame_h=None, rate_idx=3, gop_s
     hdr.put(frame_w, 16)
     hdr.put(frame_h, 16)
     hdr.put(0, 16)
-    hdr.put(0, 1)
+    if alpha is None:
+        alpha = any("coef_a" in t for t in pictures)
+    hdr.put(1 if alpha else 0, 1)                          # `a`: yuva (decoders/jsv.js:256)
     hdr.put(int(round(len(pictures) / rate * 100)), 23)
     n_hdr = 11 + (8 + 8 * len(offsets) if key_map else 0)
     if key_map:

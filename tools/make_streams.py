@@ -43,3 +43,5 @@ if __name__ == "__main__":
     # matrix never reaches the reference's GPU path, :556, so it is left at the default)
     from make_glsl_cases import CUSTOM_INTRA
     build("custom_intra_ip_48x32", 48, 32, 48, 32, [S.gop_ippp(4)], 99, qm_intra=CUSTOM_INTRA.reshape(8, 8))
+    # yuva: container flag `a` + four alpha blocks per macroblock (the repo's syntax, tools/jsv_writer.py); product parsers only
+    build("yuva_ibbp_96x64", 96, 64, 96, 64, [S.gop_ibbp(9), S.gop_ippp(4)], 404, alpha=True)
