@@ -36,6 +36,11 @@ typedef struct leon_pipeline_config {
     int32_t windows_in_flight;  /* RGBA / staging rings; <= 0: 2 */
     int32_t max_gop_pictures;   /* frames reserved per GOP in a window; <= 0: 16 */
     int32_t loop;               /* benchmarking: decode the stream this many times over (GOP ids keep counting); <= 0: once */
+    /* Frame-parallel GOP shards across the GPUs of a node: this pipeline decodes the key-map GOPs
+     * g with g % shard_count == shard_index only -- one process (or pipeline) per GPU, each with its device_id,
+     * all given the same stream; nothing is exchanged between them (closed GOPs share nothing, the key map is
+     * the stream's own index, decoders/jsv.js:264-350).  shard_count <= 1: everything. */
+    int32_t shard_index, shard_count;
 } leon_pipeline_config;
 
 /* One decoded picture.  rgba stays valid until leon_pipeline_release_window(window) */
@@ -56,6 +61,7 @@ typedef struct leon_pipeline_info {
     int32_t coded_width, coded_height, frame_width, frame_height;
     double  picture_rate, duration;
     uint32_t gops;              /* key-map entries (1 for a stream without key map) */
+    uint32_t shard_gops;        /* how many of them this pipeline decodes (per pass over the stream) */
     int32_t parser_threads, gops_per_window;
 } leon_pipeline_info;
 

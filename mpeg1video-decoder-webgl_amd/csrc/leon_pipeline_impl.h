@@ -29,7 +29,8 @@ struct Arena {                   // pinned host buffer + its device twin, one GO
 };
 
 struct GopJob {
-    uint64_t gop = 0;
+    uint64_t gop = 0;            // running index among the GOPs of this pipeline
+    uint64_t key_gop = 0;        // GOP id in the stream (key-map index, counting on across loops)
     Arena* arena = nullptr;
     std::vector<PipePic> pics;
     double gop_ts_ms = 0;
@@ -60,6 +61,7 @@ struct leon_pipeline {
     void* user = nullptr;
     leon_vlc_info vinfo{};
     std::vector<uint64_t> shard_begin, shard_end;     // byte ranges of the GOP shards
+    std::vector<uint32_t> mine;                       // key-map ids this pipeline decodes (all, or g % shard_count == shard_index)
     uint64_t total_gops = 0;                          // gops * loop
     int W = 32, R = 2, K = 1, max_pics = 16;
     size_t frame_bytes = 0;
@@ -126,7 +128,9 @@ bool arena_reserve(leon_pipeline* p, Arena* a, size_t need)
 // one GOP shard: parse every picture of it straight into a pinned arena
 void parse_gop(leon_pipeline* p, GopJob* job)
 {
-    const uint64_t g = job->gop % p->shard_begin.size();
+    // job->gop counts the GOPs this pipeline decodes; which key-map entry that is:
+    const uint64_t g = p->mine[job->gop % p->mine.size()];
+    job->key_gop = (job->gop / p->mine.size()) * p->shard_begin.size() + g;      // id in the whole (looped) stream
     const uint8_t* b = p->stream + p->shard_begin[g];
     const size_t n = (size_t)(p->shard_end[g] - p->shard_begin[g]);
     leon_vlc_stream* st = nullptr;
@@ -247,7 +251,7 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
                 lv = lv_newer + 1;
                 it.out = (int)(3 * j) + n_anchor % 3;
             } else {
-                if (newer < 0) return fail(LEON_ERR_INVALID, "GOP %llu: a B picture without an anchor (open GOPs cannot be sharded)", (unsigned long long)job->gop);
+                if (newer < 0) return fail(LEON_ERR_INVALID, "GOP %llu: a B picture without an anchor (open GOPs cannot be sharded)", (unsigned long long)job->key_gop);
                 // the leading B pictures of a closed GOP predict backward only (both references = the I picture)
                 it.bwd = newer;
                 it.fwd = older >= 0 ? older : newer;
@@ -308,7 +312,7 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
         for (size_t k = 0; k < by_disp.size(); k++) {
             if (!by_disp[k]) continue;
             leon_pipeline_frame f{};
-            f.gop = job->gop;
+            f.gop = job->key_gop;
             f.display_index = (int32_t)k;
             f.type = by_disp[k]->type;
             f.ts_ms = job->gop_ts_ms + 1000.0 * (double)k / rate;
@@ -479,7 +483,11 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
         p->shard_end.push_back(bytes);
     }
     const int loops = cfg->loop > 0 ? cfg->loop : 1;
-    p->total_gops = (uint64_t)p->shard_begin.size() * (uint64_t)loops;
+    const uint32_t sc = cfg->shard_count > 1 ? (uint32_t)cfg->shard_count : 1u, si = sc > 1 ? (uint32_t)cfg->shard_index : 0u;
+    if (si >= sc) { delete p; return fail(LEON_ERR_INVALID, "shard_index %d of %d", cfg->shard_index, cfg->shard_count); }
+    for (uint32_t g = si; g < p->shard_begin.size(); g += sc) p->mine.push_back(g);
+    if (p->mine.empty()) { delete p; return fail(LEON_ERR_INVALID, "shard %u of %u gets no GOP: the stream has %zu", si, sc, p->shard_begin.size()); }
+    p->total_gops = (uint64_t)p->mine.size() * (uint64_t)loops;
     p->W = cfg->gops_per_window > 0 ? cfg->gops_per_window : 32;
     if ((uint64_t)p->W > p->total_gops) p->W = (int)p->total_gops;
     p->R = cfg->windows_in_flight > 0 ? cfg->windows_in_flight : 2;
@@ -493,6 +501,7 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
     p->info.frame_width = p->vinfo.frame_width; p->info.frame_height = p->vinfo.frame_height;
     p->info.picture_rate = p->vinfo.picture_rate; p->info.duration = p->vinfo.duration;
     p->info.gops = (uint32_t)p->shard_begin.size();
+    p->info.shard_gops = (uint32_t)p->mine.size();
     p->info.parser_threads = p->K; p->info.gops_per_window = p->W;
     if (p->vinfo.frame_width & 7) { delete p; return fail(LEON_ERR_INVALID, "the pipeline needs frame_width %% 8 == 0 (it is %d)", p->vinfo.frame_width); }
 

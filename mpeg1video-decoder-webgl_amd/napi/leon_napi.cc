@@ -361,7 +361,9 @@ napi_value Create(napi_env env, napi_callback_info info)
 
 // ---- the native pipeline (include/leon_pipeline.h) -----------------------------------------------------
 //   const p = leon.createPipeline(streamBuffer, {deviceId, parserThreads, gopsPerWindow, windowsInFlight,
-//                                                maxGopPictures, loop}, (window, frames, status) => {...});
+//                                                maxGopPictures, loop, shardIndex, shardCount}, (window, frames, status) => {...});
+//   shardIndex / shardCount: this pipeline decodes the key-map GOPs g = shardIndex (mod shardCount) on deviceId --
+//   one Node process per GPU is the JavaScript host's form of the frame-parallel partition.
 //   frames: [{gop, displayIndex, type, ts}] in display order; window < 0 = 'ended' (decoders/jsv.js:437).
 //   p.readFrame(window, i) -> Uint8Array (copies one frame to the host: tests, thumbnails),
 //   p.releaseWindow(window), p.stats(), p.info(), p.destroy().
@@ -509,7 +511,7 @@ napi_value PipeStats(napi_env env, napi_callback_info info)
         {"seconds", s.seconds}, {"parseSecondsSum", s.parse_seconds_sum}, {"uploadBytes", s.upload_bytes}, {"entries", (double)s.entries},
         {"frameWidth", (double)h->info.frame_width}, {"frameHeight", (double)h->info.frame_height},
         {"codedWidth", (double)h->info.coded_width}, {"codedHeight", (double)h->info.coded_height},
-        {"pictureRate", h->info.picture_rate}, {"keyMapGops", (double)h->info.gops}, {"parserThreads", (double)h->info.parser_threads},
+        {"pictureRate", h->info.picture_rate}, {"keyMapGops", (double)h->info.gops}, {"shardGops", (double)h->info.shard_gops}, {"parserThreads", (double)h->info.parser_threads},
         {"gopsPerWindow", (double)h->info.gops_per_window}};
     for (auto& e : kv) {
         NAPI_OK(napi_create_double(env, e.val, &v));
@@ -555,7 +557,8 @@ napi_value CreatePipeline(napi_env env, napi_callback_info info)
     memset(&cfg, 0, sizeof cfg);
     bool ok = get_i32(env, argv[1], "deviceId", &cfg.device_id, 0) && get_i32(env, argv[1], "parserThreads", &cfg.parser_threads, 0) &&
               get_i32(env, argv[1], "gopsPerWindow", &cfg.gops_per_window, 0) && get_i32(env, argv[1], "windowsInFlight", &cfg.windows_in_flight, 0) &&
-              get_i32(env, argv[1], "maxGopPictures", &cfg.max_gop_pictures, 0) && get_i32(env, argv[1], "loop", &cfg.loop, 0);
+              get_i32(env, argv[1], "maxGopPictures", &cfg.max_gop_pictures, 0) && get_i32(env, argv[1], "loop", &cfg.loop, 0) &&
+              get_i32(env, argv[1], "shardIndex", &cfg.shard_index, 0) && get_i32(env, argv[1], "shardCount", &cfg.shard_count, 0);
     if (!ok) {
         napi_throw_type_error(env, nullptr, "createPipeline: integer options expected");
         return nullptr;

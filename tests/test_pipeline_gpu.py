@@ -165,3 +165,21 @@ def test_pipeline_errors(L):
             pipe.wait()
     finally:
         pipe.close()
+
+
+def test_gop_shards_partition_the_stream(L):
+    """two pipelines with shard_index 0 / 1 of 2 (one per GPU on a node; both on this box's device here)
+    decode disjoint GOP sets whose union is the whole stream, frames keyed by the stream's GOP ids"""
+    data = ibbp_stream(96, 64, [6, 9, 3, 12, 6], seed=31)
+    want = oracle_frames(data)
+    got = {}
+    for r in range(2):
+        part, _, stats = run_pipeline(L, data, parser_threads=2, gops_per_window=2, shard_index=r, shard_count=2)
+        assert {g for g, _ in part} == {g for g in range(5) if g % 2 == r}
+        assert not set(part) & set(got)
+        got.update(part)
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    with pytest.raises(L.LeonError):
+        L.Pipeline(data, shard_index=7, shard_count=8)       # more shards than GOPs: this one would be empty

@@ -5,6 +5,7 @@
  * only receives 'frames' events (napi_threadsafe_function); an interval timer counts how often the event
  * loop got to run meanwhile (the reference's page would be frozen inside decodeFrame for the duration).
  *   node tools/js_pipeline_bench.js <stream.jsv> [--loop 64] [--threads 16] [--window 32] [--hash]
+ *        [--device d --shard-index r --shard-count N]   (one process per GPU: tools/js_multi_gpu.js)
  * --hash: print the sha256 of every frame instead (tests; small streams).
  */
 const fs = require('fs');
@@ -22,7 +23,8 @@ const out = [];
 const timer = setInterval(() => { ticks++; }, 1);
 const t0 = process.hrtime.bigint();
 const p = new LeonPipeline(stream, { parserThreads: opt('--threads', 0), gopsPerWindow: opt('--window', 0),
-                                     windowsInFlight: opt('--inflight', 0), loop: opt('--loop', 0), autoRelease: !hash });
+                                     windowsInFlight: opt('--inflight', 0), loop: opt('--loop', 0), autoRelease: !hash,
+                                     deviceId: opt('--device', 0), shardIndex: opt('--shard-index', 0), shardCount: opt('--shard-count', 0) });
 p.on('frames', (w, fs_) => {
   windows++;
   frames += fs_.length;
