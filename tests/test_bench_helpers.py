@@ -9,20 +9,25 @@ import bench
 
 
 def test_pmc_traffic_comes_from_the_committed_profile():
-    traffic, src = bench.pmc_traffic(128)
-    assert traffic is not None and "profiles/" in src
-    path = os.path.join(ROOT, src.split(" ")[0])
-    assert os.path.exists(path), path
-    k = json.load(open(path))["kernels"]
-    assert all("void leon::k_recon<%d, false>" % t in k for t in (1, 2, 3))
-    # Fabric bytes per launch against the bytes SURVEY.md 8d counts when EVERY macroblock is charged its
-    # picture's full set of references -- per GOP and step 1 I, 3 P, 6 bidirectional and 2 backward-only B
-    # pictures.  That is what moves at 128-byte line granularity: with vectors spread over +-15 samples the
-    # macroblocks that do use a reference touch every line of it, whatever their neighbours skip
-    # (profiles/r02_fetch_calibration.json: a line is fetched whole even for 4 of its bytes).
+    """Fabric bytes per launch of the committed PMC passes against the bytes SURVEY.md 8d counts when EVERY
+    macroblock is charged its picture's full set of references -- per GOP and step 1 I, 3 P, 6 bidirectional
+    and 2 backward-only B pictures.  That is what moves at 128-byte line granularity: with vectors spread over
+    +-15 samples the macroblocks that do use a reference touch every line of it, whatever their neighbours skip
+    (profiles/r02_fetch_calibration.json: a line is fetched whole even for 4 of its bytes)."""
     mbs = (bench.CW // 16) * (bench.CH // 16)
-    planes = 128 * mbs * (1154 + 3 * 1542 + 6 * 1930 + 2 * 1542) / 8.0
-    assert 0.97 < traffic / planes < 1.06, (traffic, planes)
+    for fused in (True, False):
+        traffic, src = bench.pmc_traffic(128, fused)
+        assert traffic is not None and "profiles/" in src
+        path = os.path.join(ROOT, src.split(" ")[0])
+        assert os.path.exists(path), path
+        k = json.load(open(path))["kernels"]
+        name = "void leon::k_recon_display<%d, false>" if fused else "void leon::k_recon<%d, false>"
+        assert all(name % t in k for t in (1, 2, 3))
+        # fused display conversion: + RGBA of the 1080 displayed rows, - the planes of the B pictures
+        rgba = 1024.0 * bench.FH / bench.CH if fused else 0.0
+        b_planes = 384.0 if fused else 0.0
+        planes = 128 * mbs * ((1154 + rgba) + 3 * (1542 + rgba) + 6 * (1930 + rgba - b_planes) + 2 * (1542 + rgba - b_planes)) / 8.0
+        assert 0.97 < traffic / planes < 1.06, (fused, traffic, planes)
 
 
 def test_kernel_stats_of_the_same_round_are_committed():
