@@ -240,3 +240,19 @@ def test_gop_shards_parse_like_the_whole_stream(name):
         for k in ("coef_y", "coef_cb", "coef_cr", "repadd", "mv_fwd", "mv_bwd", "mb_dir"):
             if b.get(k) is not None:
                 assert np.array_equal(a[k], b[k]), (i, k)
+
+
+def test_corruption_fuzz_under_address_and_ub_sanitizers(tmp_path):
+    """the front end built with -fsanitize=address,undefined parses randomly damaged and truncated copies of the
+    fixture streams (yuva and B pictures included): every case ends in a clean refusal or a clean parse"""
+    if shutil.which("g++") is None:
+        pytest.skip("no g++")
+    exe = str(tmp_path / "vlc_fuzz")
+    b = subprocess.run(["g++", "-O1", "-g", "-fsanitize=address,undefined", "-fno-sanitize-recover=undefined", "-std=c++17", "-pthread",
+                        "-o", exe, os.path.join(ROOT, "tools", "vlc_fuzz.cpp"),
+                        os.path.join(ROOT, "mpeg1video-decoder-webgl_amd", "csrc", "leon_vlc.cpp")], capture_output=True, text=True, timeout=600)
+    assert b.returncode == 0, b.stderr[-2000:]
+    streams = [os.path.join(STREAMS, n + ".jsv") for n in ("leon_synth_352x240", "yuva_ibbp_96x64", "ibbp_96x64", "slices5_ip_96x64")]
+    r = subprocess.run([exe] + streams, capture_output=True, text=True, timeout=600, env=dict(os.environ, LEON_FUZZ_CASES="150"))
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert "refused" in r.stdout
