@@ -1,0 +1,28 @@
+"""GPU: bench.py's multi-rank path end to end on the one-GPU box -- `--gpus 2` starts two ranks itself, both on
+device 0 over gloo (the rehearsal knobs; RCCL needs one device per rank), each decodes its key-map slice, the
+per-GOP checksums are all-gathered and rank 0 re-decodes a GOP of the other rank and compares."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+from helpers import ROOT
+
+pytestmark = pytest.mark.gpu
+
+
+def test_two_ranks_decode_disjoint_gops_with_matching_checksums():
+    env = dict(os.environ, LEON_BENCH_BACKEND="gloo", LEON_BENCH_ONE_DEVICE="1")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gops", "4", "--unique", "2", "--steps", "2",
+                          "--warmup", "1", "--no-cpu-baseline", "--no-second-recipe"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [l for l in out.stdout.splitlines() if l.startswith("{")][-1]
+    d = json.loads(line)
+    assert d["n_gpus"] == 2 and d["config"]["pictures_per_step"] == 2 * 4 * 12
+    c = d["gop_checksums"]
+    assert c["gops"] == 8 and c["distinct"] == 8 and c["cross_rank_ok"] is True
+    assert 0.2 < d["efficiency"] < 1.2 and d["single_rank_same_run"]["value"] > 0
+    for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "roofline"):
+        assert k in d
