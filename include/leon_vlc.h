@@ -100,6 +100,11 @@ int leon_vlc_get_info(leon_vlc_stream* s, leon_vlc_info* out);
  * until the next call; leon_vlc_get_info reports the sequence state as of the last picture returned. */
 int leon_vlc_next_picture(leon_vlc_stream* s, leon_vlc_picture* out);
 
+/* The same without the parse-ahead: the picture is parsed on the calling thread, during the call (what a caller
+ * that runs one stream per thread anyway wants: the pipeline's GOP-shard parsers).  The arrays of *out stay valid
+ * until the next call.  Not to be mixed with leon_vlc_next_picture on one stream. */
+int leon_vlc_next_picture_sync(leon_vlc_stream* s, leon_vlc_picture* out);
+
 /* = jsv.prototype.seek (decoders/jsv.js:1618-1648): position on the key-map entry at or before
  * `seconds`; decoding resumes at the next sequence header.  *byte_offset receives the offset. */
 int leon_vlc_seek(leon_vlc_stream* s, double seconds, uint64_t* byte_offset);

@@ -146,7 +146,7 @@ void parse_gop(leon_pipeline* p, GopJob* job)
     a->used = 0;
     leon_vlc_picture pic;
     for (;;) {
-        const int rc = leon_vlc_next_picture(st, &pic);
+        const int rc = leon_vlc_next_picture_sync(st, &pic);      // parsed here, on this thread: no second thread per shard
         if (rc == LEON_VLC_END) break;
         if (rc != LEON_VLC_PICTURE) {
             job->status = LEON_ERR_INVALID;

@@ -1012,6 +1012,16 @@ int leon_vlc_next_picture(leon_vlc_stream* s, leon_vlc_picture* out)
     return LEON_VLC_PICTURE;
 }
 
+int leon_vlc_next_picture_sync(leon_vlc_stream* s, leon_vlc_picture* out)
+{
+    if (!s || !out) return fail(LEON_VLC_ERR_INVALID, "null argument");
+    if (s->a_inflight >= 0 || s->a_eos) return fail(LEON_VLC_ERR_INVALID, "leon_vlc_next_picture has been used on this stream: do not mix the two");
+    g_err[0] = 0;
+    const int rc = next_picture_sync(s, out);
+    s->info_out = s->info;
+    return rc;
+}
+
 int leon_vlc_seek(leon_vlc_stream* s, double seconds, uint64_t* byte_offset)
 {
     if (!s) return fail(LEON_VLC_ERR_INVALID, "null argument");

@@ -8,7 +8,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SYMBOLS = ["leon_vlc_last_error", "leon_vlc_open", "leon_vlc_close", "leon_vlc_get_info",
-           "leon_vlc_next_picture", "leon_vlc_seek", "leon_vlc_densify", "leon_vlc_densify_alpha", "leon_vlc_get_keymap"]
+           "leon_vlc_next_picture", "leon_vlc_next_picture_sync", "leon_vlc_seek", "leon_vlc_densify", "leon_vlc_densify_alpha", "leon_vlc_get_keymap"]
 
 
 class Info(C.Structure):
