@@ -41,6 +41,11 @@ typedef struct leon_pipeline_config {
      * all given the same stream; nothing is exchanged between them (closed GOPs share nothing, the key map is
      * the stream's own index, decoders/jsv.js:264-350).  shard_count <= 1: everything. */
     int32_t shard_index, shard_count;
+    /* = jsv.prototype.seek (decoders/jsv.js:1618-1648) at start-up: begin with the key-map entry at or before this
+     * time (seconds) instead of the first one; 0 = from the start.  (A running pipeline is not repositioned: a
+     * host seeks by destroying it and creating one at the new time, as the reference frees all its output
+     * buffers on a seek, jsv.js:1623.) */
+    double start_seconds;
 } leon_pipeline_config;
 
 /* One decoded picture.  rgba stays valid until leon_pipeline_release_window(window) */
@@ -62,6 +67,7 @@ typedef struct leon_pipeline_info {
     double  picture_rate, duration;
     uint32_t gops;              /* key-map entries (1 for a stream without key map) */
     uint32_t shard_gops;        /* how many of them this pipeline decodes (per pass over the stream) */
+    uint32_t first_gop;         /* key-map entry the run starts with (start_seconds) */
     int32_t parser_threads, gops_per_window;
 } leon_pipeline_info;
 

@@ -462,6 +462,13 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
     const int n_keys = leon_vlc_get_keymap(st, nullptr, nullptr, 0);
     std::vector<uint32_t> offs((size_t)std::max(n_keys, 0));
     if (n_keys > 0) leon_vlc_get_keymap(st, offs.data(), nullptr, (uint32_t)n_keys);
+    uint32_t first_gop = 0;
+    if (n_keys > 0 && cfg->start_seconds > 0) {       // the front end's own seek finds the entry (decoders/jsv.js:327-350)
+        uint64_t off = 0;
+        if (leon_vlc_seek(st, cfg->start_seconds, &off) == LEON_VLC_OK)
+            for (int g = 0; g < n_keys; g++)
+                if (offs[(size_t)g] == off) first_gop = (uint32_t)g;
+    }
     leon_vlc_close(st);
     p->cfg = *cfg;
     p->stream = stream;
@@ -485,7 +492,9 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
     const int loops = cfg->loop > 0 ? cfg->loop : 1;
     const uint32_t sc = cfg->shard_count > 1 ? (uint32_t)cfg->shard_count : 1u, si = sc > 1 ? (uint32_t)cfg->shard_index : 0u;
     if (si >= sc) { delete p; return fail(LEON_ERR_INVALID, "shard_index %d of %d", cfg->shard_index, cfg->shard_count); }
-    for (uint32_t g = si; g < p->shard_begin.size(); g += sc) p->mine.push_back(g);
+    for (uint32_t g = si; g < p->shard_begin.size(); g += sc)
+        if (g >= first_gop) p->mine.push_back(g);
+    p->info.first_gop = first_gop;
     if (p->mine.empty()) { delete p; return fail(LEON_ERR_INVALID, "shard %u of %u gets no GOP: the stream has %zu", si, sc, p->shard_begin.size()); }
     p->total_gops = (uint64_t)p->mine.size() * (uint64_t)loops;
     p->W = cfg->gops_per_window > 0 ? cfg->gops_per_window : 32;

@@ -14,6 +14,11 @@
  *
  * Beyond the reference: B pictures arrive in coded order and are re-ordered for display
  * (an I/P picture is shown when the next I/P picture has been decoded).
+ *
+ * opts.pipeline = true puts the native pipeline (leon_pipeline.js, include/leon_pipeline.h) under the same surface:
+ * parsing, reconstruction and display conversion run in native threads, whole GOPs arrive as 'frames' events in
+ * display order, the JavaScript thread only paces and hands frames out.  The queue bound is then the pipeline's:
+ * one GOP per window, two windows in flight.  Seeking recreates the pipeline at the key-map entry for the time.
  */
 const fs = require('fs');
 const { EventEmitter } = require('events');
@@ -31,10 +36,14 @@ class LeonPlayer extends EventEmitter {
    * opts.render    (rgba: Uint8Array, frame) => void, called for every displayed frame when a backend is present
    * opts.nativeParser  true: parse with libleon_vlc on worker threads and hand pictures over as sparse
    *                    group lists (native_decoder.js) instead of the JavaScript bitstream layer
+   * opts.pipeline      true: the native pipeline does everything below this class (needs frame width % 8 == 0);
+   *                    opts.parserThreads (default 4)
    */
   constructor(opts) {
     super();
-    this.opts = Object.assign({ realtime: true, backend: null, render: null, flavour: 0, nativeParser: false }, opts || {});
+    this.opts = Object.assign({ realtime: true, backend: null, render: null, flavour: 0, nativeParser: false, pipeline: false, parserThreads: 4 }, opts || {});
+    this._pipe = null;
+    this._windowLeft = new Map();      // pipeline mode: window id -> frames not displayed yet
     this.networkState = NETWORK_EMPTY;
     this.readyState = HAVE_NOTHING;
     this.paused = true;
@@ -69,6 +78,7 @@ class LeonPlayer extends EventEmitter {
   // ---- load: player/easybits.player.js:496-658 without the network ------------------------
   load() {
     this._stopTimer();
+    this._stopPipeline();
     if (this._decoder) this._decoder.destroy();
     this.networkState = NETWORK_LOADING;
     this.readyState = HAVE_NOTHING;
@@ -87,6 +97,7 @@ class LeonPlayer extends EventEmitter {
       this.emit('error', this.error);
       return;
     }
+    if (this.opts.pipeline) { this._bytes = bytes; this._startPipeline(0); if (this.autoplay) this.play(); return; }
     const Decoder = this.opts.nativeParser ? NativeJsvDecoder : JsvDecoder;
     const d = this._decoder = new Decoder({ backend: this.opts.backend, nSlots: 13 });
     d.on('meta', (m) => { this.duration = m.d; });
@@ -103,6 +114,41 @@ class LeonPlayer extends EventEmitter {
     this._fill();                                  // decode ahead: first frame -> loadeddata / canplay
     if (this.autoplay) this.play();
   }
+
+  // ---- pipeline mode: the native pipeline in place of the decoder object ---------------------------
+  _startPipeline(startSeconds) {
+    const { LeonPipeline } = require('./leon_pipeline');
+    this._stopPipeline();
+    const p = this._pipe = new LeonPipeline(Buffer.from(this._bytes.buffer, this._bytes.byteOffset, this._bytes.byteLength),
+      { backend: this.opts.backend, parserThreads: this.opts.parserThreads, gopsPerWindow: 1, windowsInFlight: 2, autoRelease: false, startSeconds });
+    const s = p.stats();
+    this.videoWidth = s.frameWidth; this.videoHeight = s.frameHeight; this.frameDuration = 1000 / (s.pictureRate || 25);
+    if (s.duration) this.duration = s.duration;
+    if (this.readyState < HAVE_METADATA) { this.readyState = HAVE_METADATA; this.emit('loadedmetadata'); }
+    this.networkState = NETWORK_IDLE;
+    p.on('frames', (w, frames) => {
+      if (p !== this._pipe) return;                 // a pipeline that has been seeked away from
+      this._windowLeft.set(w, frames.length);
+      for (const f of frames) this._decodedFrames.push(f);      // display order already
+      if (this.readyState < HAVE_CURRENT_DATA) {
+        this.readyState = HAVE_CURRENT_DATA; this.emit('loadeddata');
+        this.readyState = HAVE_FUTURE_DATA; this.emit('canplay');
+      }
+      if (this._decodedFrames.length >= MAX_DECODED_FRAMES && this.readyState < HAVE_ENOUGH_DATA) { this.readyState = HAVE_ENOUGH_DATA; this.emit('canplaythrough'); }
+      if (this.seeking) { this.seeking = false; this.emit('seeked'); }
+      if (!this.paused && !this.opts.realtime) this._drain();
+    });
+    p.on('ended', () => { if (p === this._pipe) { this._streamEnded = true; if (!this.paused && !this.opts.realtime) this._drain(); } });
+    p.on('error', (e) => { this.error = { code: 3, message: String(e.message) }; this.emit('error', this.error); });     // MEDIA_ERR_DECODE
+  }
+  _stopPipeline() {
+    if (!this._pipe) return;
+    const p = this._pipe;
+    this._pipe = null;
+    this._windowLeft.clear();
+    p.destroy();
+  }
+  _drain() { while (!this.paused && !this.ended && (this._decodedFrames.length || this._streamEnded)) this._displayFrame(); }
 
   // ---- 'frame' handler: onf, player/easybits.player.js:2543-2668 ----------------------------
   _onFrame(f) {
@@ -123,6 +169,7 @@ class LeonPlayer extends EventEmitter {
 
   // keep decoding while the queue is short (player.js:2613-2617); the slot ring (13) bounds it too
   _fill() {
+    if (this._pipe || this.opts.pipeline) return;   // the pipeline decodes ahead by itself
     const d = this._decoder;
     while (!this._streamEnded && this._decodedFrames.length < MAX_DECODED_FRAMES) {
       if (!d.decodeFrame()) break;
@@ -135,13 +182,14 @@ class LeonPlayer extends EventEmitter {
 
   // ---- play / pause: player/easybits.player.js:2235-2308 -----------------------------------
   play() {
-    if (!this._decoder) this.load();
+    if (!this._decoder && !this._pipe) this.load();
     if (this.ended) { this._seek(0); this.ended = false; }
     if (!this.paused) return;
     this.paused = false;
     this.emit('play');
     this.emit('playing');
     if (this.opts.realtime) this._timer = setInterval(() => this._displayFrame(), (this.frameDuration || 40) / this.playbackRate);
+    else if (this._pipe) this._drain();            // frames arrive as events: displayed as they come
     else while (!this.paused && !this.ended) this._displayFrame();
   }
   pause() {
@@ -169,7 +217,13 @@ class LeonPlayer extends EventEmitter {
       return;
     }
     if (f.ts) this._currentTime = f.ts / 1000; else this._currentTime += (this.frameDuration || 40) / 1000;
-    if (this._decoder.backend) {
+    if (this._pipe) {
+      // = renderFrameGL: the frame is RGBA in device memory already; a renderer gets a host copy
+      if (this.opts.render) this.opts.render(this._pipe.readFrame(f.window, f.index), f);
+      const left = this._windowLeft.get(f.window) - 1;
+      if (left > 0) this._windowLeft.set(f.window, left);
+      else { this._windowLeft.delete(f.window); this._pipe.releaseWindow(f.window); }     // = texture.inuse = false for the GOP
+    } else if (this._decoder.backend) {
       // = renderFrameGL (player.js:2787-2858), then the slot goes back to the ring (:2820)
       if (this.opts.render) this.opts.render(this._decoder.renderFrame(f, this.opts.flavour), f);
       this._decoder.releaseFrame(f);
@@ -181,6 +235,16 @@ class LeonPlayer extends EventEmitter {
 
   // ---- currentTime= -> sct -> decoder.seek: player/easybits.player.js:1423-1481, jsv.js:1618 ----
   _seek(t) {
+    if (this.opts.pipeline && this._bytes) {
+      this.seeking = true;
+      this.emit('seeking');
+      this._decodedFrames = [];
+      this._streamEnded = false;
+      this.ended = false;
+      this._currentTime = t;
+      this._startPipeline(t);                       // 'seeked' when its first frames arrive
+      return;
+    }
     if (!this._decoder) return;
     this.seeking = true;
     this.emit('seeking');
@@ -195,7 +259,7 @@ class LeonPlayer extends EventEmitter {
     this._fill();
   }
 
-  destroy() { this._stopTimer(); if (this._decoder) { this._decoder.destroy(); this._decoder = null; } }
+  destroy() { this._stopTimer(); this._stopPipeline(); if (this._decoder) { this._decoder.destroy(); this._decoder = null; } }
 }
 
 Object.assign(LeonPlayer, { NETWORK_EMPTY, NETWORK_IDLE, NETWORK_LOADING, NETWORK_NO_SOURCE,

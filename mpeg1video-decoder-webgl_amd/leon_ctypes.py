@@ -74,7 +74,7 @@ class KernelStats(C.Structure):
 class PipelineConfig(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("parser_threads", C.c_int32), ("gops_per_window", C.c_int32),
                 ("windows_in_flight", C.c_int32), ("max_gop_pictures", C.c_int32), ("loop", C.c_int32),
-                ("shard_index", C.c_int32), ("shard_count", C.c_int32)]
+                ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("start_seconds", C.c_double)]
 
 
 class PipelineFrame(C.Structure):
@@ -85,7 +85,7 @@ class PipelineFrame(C.Structure):
 class PipelineInfo(C.Structure):
     _fields_ = [("coded_width", C.c_int32), ("coded_height", C.c_int32), ("frame_width", C.c_int32), ("frame_height", C.c_int32),
                 ("picture_rate", C.c_double), ("duration", C.c_double), ("gops", C.c_uint32), ("shard_gops", C.c_uint32),
-                ("parser_threads", C.c_int32), ("gops_per_window", C.c_int32)]
+                ("first_gop", C.c_uint32), ("parser_threads", C.c_int32), ("gops_per_window", C.c_int32)]
 
 
 class PipelineStats(C.Structure):
@@ -364,7 +364,7 @@ class Pipeline:
     released right after.  read_frame(frame) works until the frame's window is released."""
 
     def __init__(self, data, device_id=0, parser_threads=0, gops_per_window=0, windows_in_flight=0, max_gop_pictures=0,
-                 loop=0, on_window=None, shard_index=0, shard_count=0):
+                 loop=0, on_window=None, shard_index=0, shard_count=0, start_seconds=0.0):
         self.lib = load()
         self._data = (C.c_uint8 * len(data)).from_buffer_copy(data)      # must outlive the pipeline
         self._on_window = on_window
@@ -395,7 +395,7 @@ class Pipeline:
                 self.error = e
         self._cb = PIPELINE_CB(_cb)
         cfg = PipelineConfig(device_id, parser_threads, gops_per_window, windows_in_flight, max_gop_pictures, loop,
-                             shard_index, shard_count)
+                             shard_index, shard_count, float(start_seconds))
         h = C.c_void_p()
         self.h = None
         rc = self.lib.leon_pipeline_create(C.byref(cfg), self._data, len(data), self._cb, None, C.byref(h))

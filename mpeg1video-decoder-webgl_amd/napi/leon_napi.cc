@@ -511,7 +511,7 @@ napi_value PipeStats(napi_env env, napi_callback_info info)
         {"seconds", s.seconds}, {"parseSecondsSum", s.parse_seconds_sum}, {"uploadBytes", s.upload_bytes}, {"entries", (double)s.entries},
         {"frameWidth", (double)h->info.frame_width}, {"frameHeight", (double)h->info.frame_height},
         {"codedWidth", (double)h->info.coded_width}, {"codedHeight", (double)h->info.coded_height},
-        {"pictureRate", h->info.picture_rate}, {"keyMapGops", (double)h->info.gops}, {"shardGops", (double)h->info.shard_gops}, {"parserThreads", (double)h->info.parser_threads},
+        {"pictureRate", h->info.picture_rate}, {"keyMapGops", (double)h->info.gops}, {"shardGops", (double)h->info.shard_gops}, {"firstGop", (double)h->info.first_gop}, {"duration", h->info.duration}, {"parserThreads", (double)h->info.parser_threads},
         {"gopsPerWindow", (double)h->info.gops_per_window}};
     for (auto& e : kv) {
         NAPI_OK(napi_create_double(env, e.val, &v));
@@ -559,6 +559,16 @@ napi_value CreatePipeline(napi_env env, napi_callback_info info)
               get_i32(env, argv[1], "gopsPerWindow", &cfg.gops_per_window, 0) && get_i32(env, argv[1], "windowsInFlight", &cfg.windows_in_flight, 0) &&
               get_i32(env, argv[1], "maxGopPictures", &cfg.max_gop_pictures, 0) && get_i32(env, argv[1], "loop", &cfg.loop, 0) &&
               get_i32(env, argv[1], "shardIndex", &cfg.shard_index, 0) && get_i32(env, argv[1], "shardCount", &cfg.shard_count, 0);
+    {   // startSeconds: begin at the key-map entry at or before this time
+        napi_value v;
+        bool has = false;
+        if (ok && napi_has_named_property(env, argv[1], "startSeconds", &has) == napi_ok && has &&
+            napi_get_named_property(env, argv[1], "startSeconds", &v) == napi_ok) {
+            napi_valuetype t;
+            napi_typeof(env, v, &t);
+            if (t == napi_number) napi_get_value_double(env, v, &cfg.start_seconds);
+        }
+    }
     if (!ok) {
         napi_throw_type_error(env, nullptr, "createPipeline: integer options expected");
         return nullptr;

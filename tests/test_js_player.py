@@ -84,3 +84,45 @@ def test_player_pixels_match_decode_order_output():
         assert s["rgba"] == by_index[s["index"]], s
     # the same playback with the native front end and the sparse boundary
     assert _run("ibbp_96x64.jsv", gpu=True, native=True)["shown"] == r["shown"]
+
+
+_PIPE_SCRIPT = r"""
+const path = require('path'), crypto = require('crypto');
+const { LeonPlayer } = require(path.join(%(js)r, 'leon_player.js'));
+const backend = require(path.join(%(js)r, '..', 'napi', 'leon_napi.node'));
+const ev = [], shown = [];
+const p = new LeonPlayer({ backend, pipeline: true, realtime: false, parserThreads: 2,
+  render: (rgba, f) => shown.push({ gop: f.gop, di: f.displayIndex, ts: f.ts, sha: crypto.createHash('sha256').update(rgba).digest('hex') }) });
+for (const e of ['loadstart', 'loadedmetadata', 'loadeddata', 'canplay', 'play', 'playing', 'seeking', 'seeked', 'ended', 'error']) p.on(e, () => ev.push(e));
+let phase = 0;
+p.on('ended', () => {
+  if (phase === 0) { phase = 1; p.currentTime = %(seek)s; p.play(); return; }
+  console.log(JSON.stringify({ ev, shown, w: p.videoWidth, h: p.videoHeight, n: p.framesDisplayed }));
+  p.destroy();
+});
+p.src = %(stream)r;
+p.play();
+"""
+
+
+@pytest.mark.gpu
+def test_player_over_the_native_pipeline():
+    """the HTML5-video-shaped surface with the native pipeline underneath: same events, frames in display order with
+    the oracle's pixels, a seek restarts at the key-map entry for the time"""
+    import hashlib
+    from test_pipeline_gpu import oracle_frames
+    path = os.path.join(STREAMS, "leon_synth_352x240.jsv")
+    want = oracle_frames(open(path, "rb").read())
+    out = subprocess.run(["node", "-e", _PIPE_SCRIPT % {"js": JSDIR, "stream": path, "seek": "0.6"}], capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-3000:]
+    r = json.loads(out.stdout.strip().splitlines()[-1])
+    assert (r["w"], r["h"]) == (352, 240) and "error" not in r["ev"]
+    assert r["ev"][:4] == ["loadstart", "loadedmetadata", "play", "playing"] or r["ev"][:2] == ["loadstart", "loadedmetadata"]
+    assert r["ev"].count("ended") == 2 and "seeking" in r["ev"] and "seeked" in r["ev"]
+    first, second = r["shown"][:24], r["shown"][24:]
+    assert [(s["gop"], s["di"]) for s in first] == [(g, d) for g in range(2) for d in range(12)]
+    assert [(s["gop"], s["di"]) for s in second] == [(1, d) for d in range(12)]          # 0.6 s = the second GOP's key entry
+    for s in r["shown"]:
+        assert s["sha"] == hashlib.sha256(want[(s["gop"], s["di"])].tobytes()).hexdigest(), s
+    ts = [s["ts"] for s in first]
+    assert ts == sorted(ts)
