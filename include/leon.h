@@ -75,7 +75,7 @@ typedef struct leon_config {
                               carry coef_a; RGBA output takes its A byte from the plane.  The reference allocates the
                               plane and never decodes it (IDCT_GL loops over three components, jsv.js:1223): A is
                               reconstructed like luma here -- same maps, luma vectors, same matrices.  Needs an even
-                              frame width; not available with the fused display conversion. */
+                              frame width. */
     int32_t reserved;
 } leon_config;
 
@@ -97,7 +97,7 @@ typedef struct leon_picture {
      * frame_width*frame_height*4 bytes, 16-byte aligned: the reconstruction kernel itself converts the
      * picture (= renderFrameGL / YCbCrToRGBA, player/easybits.player.js:2787-2858 / :2674-2785, the
      * LEON_RGB_CPU_TWIN arithmetic) instead of a later leon_convert_rgba reading the planes back.
-     * Needs frame_width % 8 == 0.  no_planes != 0: the slot's planes are not written at all -- for a
+     * Needs frame_width % 8 == 0.  (yuva decoders: the A byte of every pixel comes from the A component.)  no_planes != 0: the slot's planes are not written at all -- for a
      * picture nobody predicts from (B pictures); out_slot is then ignored (-1 is accepted). */
     void*   rgba_out;
     int32_t no_planes;

@@ -85,7 +85,8 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
 int leon_pipeline_get_info(leon_pipeline* p, leon_pipeline_info* out);
 /* the consumer is done with a window's frames: its RGBA ring entry and staging may be reused */
 int leon_pipeline_release_window(leon_pipeline* p, int64_t window);
-/* blocks until every window has been delivered (and released windows drained); returns the first error */
+/* blocks until every window has been delivered and the final callback (window -1) has returned; returns the
+ * first error.  Not to be called from inside the callback. */
 int leon_pipeline_wait(leon_pipeline* p);
 int leon_pipeline_get_stats(leon_pipeline* p, leon_pipeline_stats* out);
 /* copy one frame of a delivered, not yet released window to host memory (tests, thumbnails) */

@@ -90,6 +90,10 @@ const char* leon_vlc_last_error(void);
  * (starts with its sequence header 00 00 01 C3, see leon_vlc_get_keymap).  threads <= 0: one per hardware
  * thread, at most 16.  Reads up to the first sequence header so that leon_vlc_get_info is valid. */
 int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_stream** out);
+/* The same for a GOP shard of a stream whose container header is known to the caller: has_alpha = the
+ * leon_vlc_info.has_alpha of the whole stream (the `a` flag is in the container header, jsv.js:256-259,
+ * which a shard does not carry).  Ignored when the bytes start with a container header of their own. */
+int leon_vlc_open_shard(const uint8_t* data, size_t n, int32_t threads, int32_t has_alpha, leon_vlc_stream** out);
 void leon_vlc_close(leon_vlc_stream* s);
 int leon_vlc_get_info(leon_vlc_stream* s, leon_vlc_info* out);
 

@@ -249,7 +249,6 @@ int check_pic(const leon_decoder* d, const AnyPic& a)
             return fail(LEON_ERR_INVALID, "%u entries exceed the coefficient count of a picture", a.n_entries);
     } else if (!p.coef_y || !p.coef_cb || !p.coef_cr || !p.qscale || !p.intra) return fail(LEON_ERR_INVALID, "null boundary tensor");
     else if (d->geom.alpha && !p.coef_a) return fail(LEON_ERR_INVALID, "a yuva decoder needs coef_a");
-    if (d->geom.alpha && p.rgba_out) return fail(LEON_ERR_INVALID, "the fused display conversion is not available for yuva decoders");
     if (p.type != LEON_PIC_I) {
         if (p.ref_fwd_slot < 0 || p.ref_fwd_slot >= d->cfg.n_slots) return fail(LEON_ERR_INVALID, "ref_fwd_slot %d", p.ref_fwd_slot);
         if (!p.repadd || !p.mv_fwd) return fail(LEON_ERR_INVALID, "P/B picture without repadd/mv_fwd");
@@ -336,8 +335,19 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
     const dim3 grid(G.n_wg), block(64 * kWavesPerWG);
     // LEON_DEBUG_LDS_PAD (bytes): extra dynamic LDS per workgroup = an occupancy throttle for experiments
     static const size_t lds_pad = getenv("LEON_DEBUG_LDS_PAD") ? (size_t)atol(getenv("LEON_DEBUG_LDS_PAD")) : 0;
-    const size_t lds = kWavesPerWG * (display ? kLdsPerWaveDisplay : kLdsPerWave) + lds_pad;
-    if (display) {
+    const bool alpha = d->geom.alpha != 0;
+    const size_t lds = kWavesPerWG * (display ? (alpha ? kLdsPerWaveDisplayAlpha : kLdsPerWaveDisplay) : kLdsPerWave) + lds_pad;
+    if (display && alpha) {          // yuva: the A parts ride in the same task (k_recon_display<.., .., true>)
+        if (!sparse) {
+            if (type == LEON_PIC_I) hipLaunchKernelGGL((k_recon_display<1, false, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+            else if (type == LEON_PIC_P) hipLaunchKernelGGL((k_recon_display<2, false, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+            else hipLaunchKernelGGL((k_recon_display<3, false, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+        } else {
+            if (type == LEON_PIC_I) hipLaunchKernelGGL((k_recon_display<1, true, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+            else if (type == LEON_PIC_P) hipLaunchKernelGGL((k_recon_display<2, true, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+            else hipLaunchKernelGGL((k_recon_display<3, true, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
+        }
+    } else if (display) {
         if (!sparse) {
             if (type == LEON_PIC_I) hipLaunchKernelGGL((k_recon_display<1, false>), grid, block, lds, d->stream, d_descs, G, d->d_tables);
             else if (type == LEON_PIC_P) hipLaunchKernelGGL((k_recon_display<2, false>), grid, block, lds, d->stream, d_descs, G, d->d_tables);

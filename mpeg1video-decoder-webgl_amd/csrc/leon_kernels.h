@@ -96,6 +96,7 @@ static constexpr int kLdsStash = 2 * 512;
 // ... and the Y samples of a luma part's upper half wait for the lower half (8 rows x 64 bytes)
 static constexpr int kLdsYPark = 512;
 static constexpr int kLdsPerWaveDisplay = kLdsPerWave + kLdsStash + kLdsYPark;
+static constexpr int kLdsPerWaveDisplayAlpha = kLdsPerWaveDisplay + 1024;   // yuva: + the parked A samples of a luma part
 
 // ---- small helpers -----------------------------------------------------------
 
@@ -504,9 +505,12 @@ __device__ __forceinline__ uint32_t pred_x256(uint32_t pred)
 // two luma parts (CHROMA = false, 4 macroblocks each), whose lanes hold 8 horizontally adjacent Y samples
 // and find their 4 Cb and 4 Cr samples in the stash.
 struct Display {
-    char* stash;                 // LDS: [Cb | Cr][8 rows][64 bytes]
+    char* stash;                 // LDS: [Cb | Cr][8 rows][64 bytes], then the parked Y rows of a luma part's upper half
     int side;                    // luma parts: 0 / 1 = left / right four macroblocks of the chroma group
+    char* apark;                 // yuva: the A samples of the four macroblocks, [half][8 rows][64 bytes]
 };
+// AMODE of recon_task in a yuva display task: the A part runs before the Y part of the same four macroblocks
+// and parks its samples (1); the Y part's conversion takes its alpha bytes from there (2); 0 otherwise.
 
 // Uint8ClampedArray store: clamp, round half to even (2^52+2^51 trick; |x| < 2^31)
 __device__ __forceinline__ uint32_t u8_clamped(double x);
@@ -514,7 +518,7 @@ __device__ __forceinline__ uint32_t u8_clamped(double x);
 // 4 horizontally adjacent pixels: Y samples y4 (one packed dword), chroma samples cb2 / cr2 (one per
 // pixel pair, two packed bytes each) -> 4 RGBA dwords; the operations and their order are those of
 // k_rgba_twin4 (= the reference's YCbCrToRGBA, player/easybits.player.js:2692-2782)
-__device__ __forceinline__ v4u rgba_row4(uint32_t y4, uint32_t cb2, uint32_t cr2)
+__device__ __forceinline__ v4u rgba_row4(uint32_t y4, uint32_t cb2, uint32_t cr2, uint32_t a4 = 0xffffffffu)
 {
     uint32_t px[4];
 #pragma unroll
@@ -527,7 +531,7 @@ __device__ __forceinline__ v4u rgba_row4(uint32_t y4, uint32_t cb2, uint32_t cr2
         for (int k = 0; k < 2; k++) {
             const int i = 2 * q + k;
             const double ys = ((double)((y4 >> (8 * i)) & 255u) - 16.0) * 1.16438;
-            px[i] = u8_clamped(r + ys) | (u8_clamped(g + ys) << 8) | (u8_clamped(b + ys) << 16) | 0xff000000u;
+            px[i] = u8_clamped(r + ys) | (u8_clamped(g + ys) << 8) | (u8_clamped(b + ys) << 16) | (((a4 >> (8 * i)) & 255u) << 24);
         }
     }
     return v4u{px[0], px[1], px[2], px[3]};
@@ -536,7 +540,7 @@ __device__ __forceinline__ v4u rgba_row4(uint32_t y4, uint32_t cb2, uint32_t cr2
 // `alpha` (wave-uniform, luma-shaped tasks only): the task reconstructs the A plane of a yuva picture --
 // the same code path as luma with its own coefficient plane, the plane behind Cr in every slot, and the
 // alpha groups of the sparse lists.
-template <int TYPE, bool CHROMA, bool SPARSE, bool DISPLAY>
+template <int TYPE, bool CHROMA, bool SPARSE, bool DISPLAY, int AMODE = 0>
 __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, const Tables* __restrict__ Tg,
                                            int Rt, int g, char* lds, int lane, Display dsp, bool alpha = false)
 {
@@ -823,6 +827,9 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             if constexpr (CHROMA) {
                 // park the samples for the luma parts: [plane = half][row hi3][8 bytes of macroblock lo3]
                 *reinterpret_cast<v2u*>(dsp.stash + half * 512 + hi3 * 64 + lo3 * 8) = o;
+            } else if constexpr (AMODE == 1) {
+                // yuva, A part: the samples wait for the Y part of the same macroblocks
+                *reinterpret_cast<v2u*>(dsp.apark + half * 512 + hi3 * 64 + lo3 * 8) = o;
             } else {
                 // converted after both halves (stage 5): the upper half's rows wait behind the stash, the
                 // lower half's in the coefficient tile, which is free by then
@@ -834,7 +841,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    if constexpr (DISPLAY && !CHROMA) {
+    if constexpr (DISPLAY && !CHROMA && AMODE != 1) {
         // ---- stage 5 (fused display conversion): RGBA of the 64 x 16 strip ---------------------------
         // Done after both halves: nothing of the reconstruction is live any more (in place after each half
         // the conversion's fp64 temporaries came on top of the next half's prefetched reference rows and cost
@@ -855,16 +862,21 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             const uint32_t ya = *reinterpret_cast<const uint32_t*>(yp), yb = *reinterpret_cast<const uint32_t*>(yp + 32);
             const uint32_t cba = *reinterpret_cast<const uint16_t*>(sp), cra = *reinterpret_cast<const uint16_t*>(sp + 512);
             const uint32_t cbb = *reinterpret_cast<const uint16_t*>(sp + 16), crb = *reinterpret_cast<const uint16_t*>(sp + 528);
+            uint32_t aa = 0xffffffffu, ab = 0xffffffffu;           // yuva: the pixels' A samples, parked by the A part
+            if constexpr (AMODE == 2) {
+                const char* ap = dsp.apark + half * 512 + hi3 * 64 + lo3 * 4;
+                aa = *reinterpret_cast<const uint32_t*>(ap);
+                ab = *reinterpret_cast<const uint32_t*>(ap + 32);
+            }
             // the frame is the top-left crop of the coded picture; its width is a multiple of 8 (host check)
             const uint32_t row_off = (uint32_t)yrow * (uint32_t)G.fw;
             const bool in_a = yrow < G.fh && xa < G.fw, in_b = yrow < G.fh && xa + 32 < G.fw;
-            // one quad after the other (scheduling barriers): the four quads interleaved for instruction-level
-            // parallelism need 93 registers on the B path = 5 waves per SIMD instead of 7
+            // one quad after the other
             __builtin_amdgcn_sched_barrier(0);
-            const v4u pa = rgba_row4(ya, cba, cra);
+            const v4u pa = rgba_row4(ya, cba, cra, aa);
             __builtin_amdgcn_raw_buffer_store_b128(pa, rrs, (int)(((row_off + (uint32_t)xa) * 4u) | (in_a ? 0u : kOobBit)), 0, 0);
             __builtin_amdgcn_sched_barrier(0);
-            const v4u pb = rgba_row4(yb, cbb, crb);
+            const v4u pb = rgba_row4(yb, cbb, crb, ab);
             __builtin_amdgcn_raw_buffer_store_b128(pb, rrs, (int)(((row_off + (uint32_t)xa + 32u) * 4u) | (in_b ? 0u : kOobBit)), 0, 0);
             __builtin_amdgcn_sched_barrier(0);
         }
@@ -925,7 +937,7 @@ __global__ __launch_bounds__(kReconMaxThreads) void k_recon(const PicDesc* __res
 // The same reconstruction with the display conversion fused in (see Display above).  One wave = the 8
 // macroblocks of one chroma group, all components: tasks_per_pic = tasksC here (the host sets Geom up
 // for that), the chroma part first, then the left and the right luma part.
-template <int TYPE, bool SPARSE>
+template <int TYPE, bool SPARSE, bool ALPHA = false>
 __global__ __launch_bounds__(kReconMaxThreads) void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
                                                                     const Tables* __restrict__ T)
 {
@@ -936,17 +948,28 @@ __global__ __launch_bounds__(kReconMaxThreads) void k_recon_display(const PicDes
     const int pic = div_inv(wg, G.inv_wg_per_pic);
     const int t = (wg - pic * G.wg_per_pic) * kWavesPerWG + wave;
     if (t >= G.tasks_per_pic) return;
-    char* lds = smem + wave * kLdsPerWaveDisplay;
+    char* lds = smem + wave * (ALPHA ? kLdsPerWaveDisplayAlpha : kLdsPerWaveDisplay);
     const PicDesc& pd = descs[pic];
     const int Rt = div_inv(t, G.inv_gC), gc = t - Rt * G.gC;
-    Display dsp{lds + kLdsPerWave, 0};
+    Display dsp{lds + kLdsPerWave, 0, lds + kLdsPerWaveDisplay};
     recon_task<TYPE, true, SPARSE, true>(pd, G, T, Rt, gc, lds, lane, dsp);
-    // the two luma parts as two calls, not a loop: the loop form keeps 15 more registers live (B path: 93)
+    // the two luma parts as two calls, not a loop: the loop form keeps 15 more registers live (B path: 93).
+    // yuva: the A part of the same four macroblocks first (AMODE 1), then the Y part that displays them (AMODE 2).
     dsp.side = 0;
-    recon_task<TYPE, false, SPARSE, true>(pd, G, T, Rt, 2 * gc, lds, lane, dsp);
+    if constexpr (ALPHA) {
+        recon_task<TYPE, false, SPARSE, true, 1>(pd, G, T, Rt, 2 * gc, lds, lane, dsp, true);
+        recon_task<TYPE, false, SPARSE, true, 2>(pd, G, T, Rt, 2 * gc, lds, lane, dsp);
+    } else {
+        recon_task<TYPE, false, SPARSE, true>(pd, G, T, Rt, 2 * gc, lds, lane, dsp);
+    }
     if (2 * gc + 1 < G.gY) {
         dsp.side = 1;
-        recon_task<TYPE, false, SPARSE, true>(pd, G, T, Rt, 2 * gc + 1, lds, lane, dsp);
+        if constexpr (ALPHA) {
+            recon_task<TYPE, false, SPARSE, true, 1>(pd, G, T, Rt, 2 * gc + 1, lds, lane, dsp, true);
+            recon_task<TYPE, false, SPARSE, true, 2>(pd, G, T, Rt, 2 * gc + 1, lds, lane, dsp);
+        } else {
+            recon_task<TYPE, false, SPARSE, true>(pd, G, T, Rt, 2 * gc + 1, lds, lane, dsp);
+        }
     }
 }
 

@@ -135,7 +135,7 @@ void parse_gop(leon_pipeline* p, GopJob* job)
     const size_t n = (size_t)(p->shard_end[g] - p->shard_begin[g]);
     leon_vlc_stream* st = nullptr;
     // a stream without key map is one shard that still carries its container header
-    if (leon_vlc_open(b, n, 1, &st) != LEON_VLC_OK) {
+    if (leon_vlc_open_shard(b, n, 1, p->vinfo.has_alpha, &st) != LEON_VLC_OK) {
         job->status = LEON_ERR_INVALID;
         job->err = std::string("GOP shard ") + std::to_string(g) + ": " + leon_vlc_last_error();
         return;
@@ -438,11 +438,16 @@ void notify_main(leon_pipeline* p)
     bool quiet;
     {
         std::lock_guard<std::mutex> lk(p->mu);
-        p->finished = true;
         quiet = p->quiet;
     }
+    // 'ended' (or the error that stopped the run) BEFORE leon_pipeline_wait returns: a host that waits and then
+    // looks at what its callback recorded must find the end recorded
+    if (p->cb && !quiet) p->cb(p->user, -1, nullptr, 0, p->status);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        p->finished = true;
+    }
     p->cv.notify_all();
-    if (p->cb && !quiet) p->cb(p->user, -1, nullptr, 0, p->status);     // 'ended' (or the error that stopped the run)
 }
 
 }  // namespace
@@ -518,6 +523,7 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
     dc.coded_width = p->vinfo.coded_width; dc.coded_height = p->vinfo.coded_height;
     dc.frame_width = p->vinfo.frame_width; dc.frame_height = p->vinfo.frame_height;
     dc.n_slots = 3 * p->W;
+    dc.alpha = p->vinfo.has_alpha == 1;        // yuva: the frames' A bytes come from the stream's fourth component
     dc.device_id = cfg->device_id;
     int rc = leon_create(&dc, &p->dec);
     if (rc != LEON_OK) { delete p; return rc; }

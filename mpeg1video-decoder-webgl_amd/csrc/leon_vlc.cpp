@@ -806,6 +806,11 @@ const char* leon_vlc_last_error(void) { return g_err; }
 
 int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_stream** out)
 {
+    return leon_vlc_open_shard(data, n, threads, -1, out);
+}
+
+int leon_vlc_open_shard(const uint8_t* data, size_t n, int32_t threads, int32_t has_alpha, leon_vlc_stream** out)
+{
     if (!data || !out || n < 12) return fail(LEON_VLC_ERR_INVALID, "null or too short stream");
     leon_vlc_stream* s = new (std::nothrow) leon_vlc_stream();
     if (!s) return fail(LEON_VLC_ERR_NOMEM, "out of memory");
@@ -819,7 +824,7 @@ int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_strea
     s->raw_es = data[0] == 0 && data[1] == 0 && data[2] == 1 && data[3] == START_SEQUENCE_ES;
     // a GOP shard cut out of a JSV stream at a key-map entry starts with the JSV sequence header itself
     const bool shard = data[0] == 0 && data[1] == 0 && data[2] == 1 && data[3] == START_SEQUENCE;
-    s->info.has_alpha = -1;
+    s->info.has_alpha = shard && has_alpha == 1 ? 1 : -1;      // the flag lives in the container header a shard lacks
     if (!s->raw_es && !shard) {
         // container header: decoders/jsv.js:237-313
         r.skip(16);

@@ -46,11 +46,13 @@ def oracle_frames(data):
             bwd, fwd = newer, (older if older is not None else newer)
         planes = O.decode_picture(p["type"], cw, ch, p["coef_y"], p["coef_cb"], p["coef_cr"], p["qscale"], p["intra"],
                                   repadd=p.get("repadd"), mb_dir=p.get("mb_dir"), mv_fwd=p.get("mv_fwd"), mv_bwd=p.get("mv_bwd"),
-                                  qm=qm, ref_fwd=fwd, ref_bwd=bwd)
+                                  qm=qm, ref_fwd=fwd, ref_bwd=bwd, coef_a=p.get("coef_a"))
         if p["type"] != 3:
             older, newer = newer, planes
-        y, cb, cr = O.split_planes(planes, cw, ch)
-        out[(gop, p["temporal_reference"])] = O.ycbcr_to_rgba(y, cb, cr, cw, fw, fh, "cpu")
+        n3 = cw * ch * 3 // 2
+        y, cb, cr = O.split_planes(planes[:n3], cw, ch)
+        out[(gop, p["temporal_reference"])] = O.ycbcr_to_rgba(y, cb, cr, cw, fw, fh, "cpu",
+                                                               a=planes[n3:] if p.get("coef_a") is not None else None)
     return out
 
 
@@ -95,6 +97,18 @@ def test_fixture_streams(L, name):
     for k in want:
         assert np.array_equal(got[k], want[k]), "%s: frame %s differs" % (name, k)
     assert order == sorted(order)                       # GOP-major, display order inside a GOP
+
+
+def test_yuva_stream(L):
+    """a yuva stream (container flag `a`): the GOP shards are opened with the whole stream's flag
+    (leon_vlc_open_shard) and the frames' A bytes are the decoded fourth component"""
+    data = open(os.path.join(STREAMS, "yuva_ibbp_96x64.jsv"), "rb").read()
+    want = oracle_frames(data)
+    assert any((rgba.reshape(-1, 4)[:, 3] != 255).any() for rgba in want.values())
+    got, order, stats = run_pipeline(L, data, parser_threads=2, gops_per_window=2)
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
 
 
 @pytest.mark.parametrize("window,threads,inflight", [(1, 1, 1), (3, 4, 2), (8, 2, 3)])
