@@ -2,6 +2,7 @@
 // Compiled with hipcc -x hip; see mpeg1video-decoder-webgl_amd/csrc/Makefile.
 // There is no CPU path in this library: without a device every call fails.
 #include "leon_kernels.h"
+#include "leon_rgba_lut.h"
 #include "../../include/leon.h"
 
 #include <hip/hip_runtime.h>
@@ -198,6 +199,8 @@ void upload_tables(leon_decoder* d)
             d->h_tables.qmT[1][c][i] = d->qm[64 + i * 8 + c];
             d->h_tables.pmT[c][i] = kPremultiplier[i * 8 + c];
         }
+    static_assert(LEON_RGBA_LUT_SHIFT == kLutShift && sizeof(kLeonRgbaLut) == sizeof(d->h_tables.rgba_lut), "leon_rgba_lut.h and leon_kernels.h disagree");
+    memcpy(d->h_tables.rgba_lut, kLeonRgbaLut, sizeof(kLeonRgbaLut));
 }
 
 int n_groups_of(const Geom& G) { return 2 * G.tasksY + 2 * G.tasksC + (G.alpha ? 2 * G.tasksY : 0); }
@@ -336,7 +339,7 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
     // LEON_DEBUG_LDS_PAD (bytes): extra dynamic LDS per workgroup = an occupancy throttle for experiments
     static const size_t lds_pad = getenv("LEON_DEBUG_LDS_PAD") ? (size_t)atol(getenv("LEON_DEBUG_LDS_PAD")) : 0;
     const bool alpha = d->geom.alpha != 0;
-    const size_t lds = kWavesPerWG * (display ? (alpha ? kLdsPerWaveDisplayAlpha : kLdsPerWaveDisplay) : kLdsPerWave) + lds_pad;
+    const size_t lds = kWavesPerWG * (display ? (alpha ? kLdsPerWaveDisplayAlpha : kLdsPerWaveDisplay) : kLdsPerWave) + lds_pad;      // display kernels: + kLdsLut of static LDS (the conversion tables)
     if (display && alpha) {          // yuva: the A parts ride in the same task (k_recon_display<.., .., true>)
         if (!sparse) {
             if (type == LEON_PIC_I) hipLaunchKernelGGL((k_recon_display<1, false, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);

@@ -78,6 +78,7 @@ struct Geom {
 struct Tables {                  // T6, per sequence
     uint8_t qmT[2][8][8];        // [0 intra | 1 non-intra][column c][row i] = Q[i][c]
     uint8_t pmT[8][8];           // premultiplier, [column c][row i]
+    int32_t rgba_lut[1280];      // fused display conversion: fixed-point terms of YCbCrToRGBA (leon_rgba_lut.h)
 };
 
 static constexpr int kWavesPerWG = 4;
@@ -93,9 +94,9 @@ static constexpr int kLdsPerWave = kLdsCoef + kLdsHandoff;
 // fused display conversion: the Cb and Cr samples of the task's 8 macroblocks (8 rows x 64 bytes each)
 // wait in LDS for the luma parts of the same task
 static constexpr int kLdsStash = 2 * 512;
-// ... and the Y samples of a luma part's upper half wait for the lower half (8 rows x 64 bytes)
-static constexpr int kLdsYPark = 512;
-static constexpr int kLdsPerWaveDisplay = kLdsPerWave + kLdsStash + kLdsYPark;
+static constexpr int kLdsPerWaveDisplay = kLdsPerWave + kLdsStash;
+static constexpr int kLdsLut = 1280 * 4;         // display kernels: Tables::rgba_lut, one copy per workgroup, in front of the waves' strips
+static constexpr int kLutShift = 21;             // = LEON_RGBA_LUT_SHIFT (static_assert in leon_hip.cpp)
 static constexpr int kLdsPerWaveDisplayAlpha = kLdsPerWaveDisplay + 1024;   // yuva: + the parked A samples of a luma part
 
 // ---- small helpers -----------------------------------------------------------
@@ -144,12 +145,21 @@ constexpr uint32_t kOobBit = 0x80000000u;
 // The reference rows are re-read by neighbouring groups and must keep their place in L1/L2;
 // measured +3 % on the bench workload (sc0 / sc1 on the same loads: nothing; nt on the stores: -4 %).
 constexpr int kAuxStreamOnce = 2;
-// per-lane offset + wave-uniform offset (the scalar part is not range checked)
-__device__ __forceinline__ v4i buf_load_v4i_s(__amdgpu_buffer_rsrc_t rs, uint32_t voff, uint32_t soff)
+// The dense boundary's coefficient rows go from memory straight into the wave's LDS tile (gfx950:
+// buffer_load_dwordx4 ... lds; lane i's 16 bytes land at tile + 16 i, the layout stage 1 reads) -- no registers
+// in between (four VGPRs held across half a task cost the B path a wave of occupancy) and no ds_write.  The
+// compiler does not order LDS reads behind such a load; the waits are explicit (wait_vmem_all) and sit where
+// everything outstanding has long arrived: in front of the reference fetches of a task and in front of the
+// stores of a half.  Lanes that must not load (kOobBit) get zeros.
+__device__ __forceinline__ void coef_rows_to_lds(const void* plane, char* tile, uint32_t voff, uint32_t soff)
 {
-    v4u r = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)voff, (int)soff, kAuxStreamOnce);
-    return v4i{(int)r.x, (int)r.y, (int)r.z, (int)r.w};
+    const __amdgpu_buffer_rsrc_t rs = buf_rsrc(plane);
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)tile, 16, (int)voff, (int)soff, 0, kAuxStreamOnce);
 }
+// every vector memory operation of this wave has completed (loads, LDS-direct loads, stores)
+__device__ __forceinline__ void wait_vmem_all() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+__device__ __forceinline__ void wait_lds_all() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+
 // lanes whose value is non-zero, as a scalar mask: ONE v_cmp (the ballot builtin on a
 // 16-bit-derived compare costs three vector instructions with this compiler)
 __device__ __forceinline__ uint64_t lanes_nonzero(int v)
@@ -508,33 +518,101 @@ struct Display {
     char* stash;                 // LDS: [Cb | Cr][8 rows][64 bytes], then the parked Y rows of a luma part's upper half
     int side;                    // luma parts: 0 / 1 = left / right four macroblocks of the chroma group
     char* apark;                 // yuva: the A samples of the four macroblocks, [half][8 rows][64 bytes]
+    const char* lut;             // LDS copy of Tables::rgba_lut (the workgroup's)
 };
 // AMODE of recon_task in a yuva display task: the A part runs before the Y part of the same four macroblocks
 // and parks its samples (1); the Y part's conversion takes its alpha bytes from there (2); 0 otherwise.
 
-// Uint8ClampedArray store: clamp, round half to even (2^52+2^51 trick; |x| < 2^31)
-__device__ __forceinline__ uint32_t u8_clamped(double x);
-
-// 4 horizontally adjacent pixels: Y samples y4 (one packed dword), chroma samples cb2 / cr2 (one per
-// pixel pair, two packed bytes each) -> 4 RGBA dwords; the operations and their order are those of
-// k_rgba_twin4 (= the reference's YCbCrToRGBA, player/easybits.player.js:2692-2782)
-__device__ __forceinline__ v4u rgba_row4(uint32_t y4, uint32_t cb2, uint32_t cr2, uint32_t a4 = 0xffffffffu)
+// byte i of a packed dword, times 2^sh: one v_lshlrev_b32_sdwa (table addresses from packed samples)
+template <int I>
+__device__ __forceinline__ uint32_t byte_shl(uint32_t v, uint32_t sh)
 {
-    uint32_t px[4];
-#pragma unroll
-    for (int q = 0; q < 2; q++) {
-        const double yuvr = (double)((cr2 >> (8 * q)) & 255u) - 128.0, yuvb = (double)((cb2 >> (8 * q)) & 255u) - 128.0;
-        const double r = yuvr * 1.59603;
-        const double g = (-0.81297 * yuvr) - (0.39176 * yuvb);
-        const double b = yuvb * 2.01723;
-#pragma unroll
-        for (int k = 0; k < 2; k++) {
-            const int i = 2 * q + k;
-            const double ys = ((double)((y4 >> (8 * i)) & 255u) - 16.0) * 1.16438;
-            px[i] = u8_clamped(r + ys) | (u8_clamped(g + ys) << 8) | (u8_clamped(b + ys) << 16) | (((a4 >> (8 * i)) & 255u) << 24);
-        }
+    uint32_t d;
+    if constexpr (I == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(d) : "v"(sh), "v"(v));
+    else if constexpr (I == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(d) : "v"(sh), "v"(v));
+    else if constexpr (I == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(d) : "v"(sh), "v"(v));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(d) : "v"(sh), "v"(v));
+    return d;
+}
+
+// The reference's YCbCrToRGBA (player/easybits.player.js:2692-2782) on fixed-point tables: every term of
+//   R = store(r(Cr) + ys(Y)), G = store((g1(Cr) - g2(Cb)) + ys(Y)), B = store(b(Cb) + ys(Y))
+// (store = Uint8ClampedArray: clamp, round half to even) comes out of an LDS table with 21 fractional bits,
+// the sum is shifted, clamped and packed by v_ashr_pk_u8_i32 -- and equals the fp64 arithmetic for all 2^24
+// inputs (tools/make_rgba_lut.py explains why and checks it; tests/test_rgba_lut.py, and the exhaustive GPU
+// test in tests/test_fused_display_gpu.py).  7 vector instructions per pixel instead of 20 in fp64.
+struct ChromaTerms { int r, g, b; };
+template <int I>
+__device__ __forceinline__ ChromaTerms chroma_terms(const char* lut, uint32_t cb2, uint32_t cr2, uint32_t three)
+{
+    const v2u rc = *reinterpret_cast<const v2u*>(lut + 1024 + byte_shl<I>(cr2, three));     // {r, g1}[Cr]
+    const v2u bc = *reinterpret_cast<const v2u*>(lut + 3072 + byte_shl<I>(cb2, three));     // {b, -g2}[Cb]
+    return ChromaTerms{(int)rc.x, (int)(rc.y + bc.y), (int)bc.x};
+}
+template <int I>
+__device__ __forceinline__ uint32_t rgba_px(const char* lut, uint32_t y4, const ChromaTerms& c, int a_fixed, uint32_t two)
+{
+    const int ys = *reinterpret_cast<const int*>(lut + byte_shl<I>(y4, two));
+    // {sat_u8(a >> 21), sat_u8(b >> 21)} in the low 16 bits; the upper 16 are not defined (the instruction leaves
+    // them alone) and not used: the byte permute takes bytes 0..1 of each.  Through asm: the builtin returns 16
+    // bits and the compiler would widen each result with an AND first.
+    uint32_t rg, ba;
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(rg) : "v"(ys + c.r), "v"(ys + c.g), "n"(kLutShift));
+    asm("v_ashr_pk_u8_i32 %0, %1, %2, %3" : "=v"(ba) : "v"(ys + c.b), "v"(a_fixed), "n"(kLutShift));
+    return __builtin_amdgcn_perm(ba, rg, 0x05040100u);
+}
+// 4 horizontally adjacent pixels of one row: Y samples y4, the two chroma pairs' terms, A samples a4
+template <bool ALPHA>
+__device__ __forceinline__ v4u rgba_row4(const char* lut, uint32_t y4, const ChromaTerms& c0, const ChromaTerms& c1, uint32_t a4,
+                                         uint32_t two, uint32_t k21)
+{
+    const int opaque = 255 << kLutShift;
+    int a[4] = {opaque, opaque, opaque, opaque};
+    if constexpr (ALPHA) {
+        a[0] = (int)byte_shl<0>(a4, k21); a[1] = (int)byte_shl<1>(a4, k21);
+        a[2] = (int)byte_shl<2>(a4, k21); a[3] = (int)byte_shl<3>(a4, k21);
     }
-    return v4u{px[0], px[1], px[2], px[3]};
+    return v4u{rgba_px<0>(lut, y4, c0, a[0], two), rgba_px<1>(lut, y4, c0, a[1], two),
+               rgba_px<2>(lut, y4, c1, a[2], two), rgba_px<3>(lut, y4, c1, a[3], two)};
+}
+
+// ---- stage 5 (fused display conversion): RGBA of one half (64 x 8 samples) of a luma part ---------------
+// A lane of recon_task holds samples 8b .. 8b+7 of row n; converted as they lie, a store instruction would
+// write 16-byte pieces 32 bytes apart (half-filled lines) and the two rows that share a chroma row would
+// sit in different lanes.  So the rows went through LDS (`ypark`: [8 rows][64 bytes], written at the end of
+// the half and ordered by the fences there) and lane (n, b) converts the pixel quad j = 2b + (n & 1) of the
+// row pair p = n >> 1: pixels 4j .. 4j+3 of rows 2p and 2p+1, whose chroma terms it looks up once; a store
+// instruction writes 256 contiguous bytes of each of four rows = full 128-byte lines.
+template <int AMODE>
+__device__ __forceinline__ void display_half(const PicDesc& pd, const Geom& G, const Display& dsp, const char* ypark,
+                                             int half, int Rt, int g, int hi3, int lo3)
+{
+    const int pr = hi3 >> 1, jq = 2 * lo3 + (hi3 & 1);
+    const int xa = 64 * g + 4 * jq;                            // first pixel of the lane's quad
+    const __amdgpu_buffer_rsrc_t rrs = buf_rsrc(pd.rgba);
+    uint32_t two = 2u, three = 3u, k21 = (uint32_t)kLutShift;  // SDWA shift counts live in registers
+    asm("" : "+v"(two), "+v"(three));
+    if constexpr (AMODE == 2) asm("" : "+v"(k21));
+    const int yrow = 8 * (2 * Rt + half) + 2 * pr;
+    // chroma: row y>>1 = stash row 4*half + p; the quad's two chroma samples are bytes 32*side + 2j, + 1
+    const char* yp = ypark + pr * 128 + jq * 4;
+    const char* sp = dsp.stash + (4 * half + pr) * 64 + 32 * dsp.side + 2 * jq;
+    const uint32_t ya = *reinterpret_cast<const uint32_t*>(yp), yb = *reinterpret_cast<const uint32_t*>(yp + 64);
+    const uint32_t cb2 = *reinterpret_cast<const uint16_t*>(sp), cr2 = *reinterpret_cast<const uint16_t*>(sp + 512);
+    uint32_t aa = 0u, ab = 0u;                             // yuva: the pixels' A samples, parked by the A part
+    if constexpr (AMODE == 2) {
+        const char* ap = dsp.apark + half * 512 + pr * 128 + jq * 4;
+        aa = *reinterpret_cast<const uint32_t*>(ap);
+        ab = *reinterpret_cast<const uint32_t*>(ap + 64);
+    }
+    const ChromaTerms c0 = chroma_terms<0>(dsp.lut, cb2, cr2, three), c1 = chroma_terms<1>(dsp.lut, cb2, cr2, three);
+    // the frame is the top-left crop of the coded picture; its width is a multiple of 8 (host check)
+    const uint32_t row_off = __umul24((uint32_t)yrow, (uint32_t)G.fw) + (uint32_t)xa;     // both < 4096
+    const bool in_a = yrow < G.fh && xa < G.fw, in_b = yrow + 1 < G.fh && xa < G.fw;
+    const v4u pa = rgba_row4<AMODE == 2>(dsp.lut, ya, c0, c1, aa, two, k21);
+    __builtin_amdgcn_raw_buffer_store_b128(pa, rrs, (int)((row_off * 4u) | (in_a ? 0u : kOobBit)), 0, 0);
+    const v4u pb = rgba_row4<AMODE == 2>(dsp.lut, yb, c0, c1, ab, two, k21);
+    __builtin_amdgcn_raw_buffer_store_b128(pb, rrs, (int)(((row_off + (uint32_t)G.fw) * 4u) | (in_b ? 0u : kOobBit)), 0, 0);
 }
 
 // `alpha` (wave-uniform, luma-shaped tasks only): the task reconstructs the A plane of a yuva picture --
@@ -571,7 +649,6 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     // a table indexed by the scale would put a second dependent memory round trip here)
     const int R0 = CHROMA ? Rt : 2 * Rt;
     const uint32_t coef_voff = (2u * ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)(8 * Qld))) | (ld_ok ? 0u : kOobBit);
-    v4i cv_next = {0, 0, 0, 0};
     // sparse boundary: the two groups of the task are two runs of entries[]; the first 64
     // entries of each are requested here (one dword per lane), longer runs loop in stage 1
     uint32_t ent_first[2] = {0u, 0u}, ent_start[2] = {0u, 0u}, ent_count[2] = {0u, 0u};
@@ -593,7 +670,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
                 ent_rs, (int)(((s0 + (uint32_t)lane) * 4u) | ((uint32_t)lane < ent_count[h] ? 0u : kOobBit)), 0, kAuxStreamOnce);
         }
     } else {
-        cv_next = buf_load_v4i_s(buf_rsrc(pd.coef[CHROMA ? 1 : (alpha ? 3 : 0)]), coef_voff, 0u);
+        coef_rows_to_lds(pd.coef[CHROMA ? 1 : (alpha ? 3 : 0)], lds, coef_voff, 0u);
     }
     const v2u mI = ldg<v2u>(T, (uint32_t)c * 8u), mN = ldg<v2u>(T, 64u + (uint32_t)c * 8u);
     const v2u pm8 = ldg<v2u>(T, 128u + (uint32_t)c * 8u);
@@ -665,6 +742,8 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     const bool any_f = TYPE != 3 || __builtin_amdgcn_ballot_w64(useA) != 0;
     const bool any_b = TYPE == 3 && __builtin_amdgcn_ballot_w64(useB) != 0;
     if (TYPE != 1) {
+        // the first half's coefficient rows (requested before the maps these fetches wait for anyway)
+        if constexpr (!SPARSE) wait_vmem_all();
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int Rh = CHROMA ? Rt : 2 * Rt + h;
@@ -677,19 +756,16 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     for (int half = 0; half < 2; half++) {
         const uint32_t plane_off = CHROMA ? (half == 0 ? ysz : ysz + (ysz >> 2)) : a_off;
 
-        // ---- stage 0: this half's coefficient rows were requested a half earlier; request the
-        //      next half's now so that their HBM latency hides behind this half's arithmetic
-        const v4i cv = cv_next;
-        if constexpr (!SPARSE) {
-            // always issued; in the last half the resource has no records, so nothing is fetched
-            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-                (void*)pd.coef[CHROMA ? 2 : (alpha ? 3 : 0)], 0, half == 0 ? 0x7fffffff : 0, 0x00020000);
-            cv_next = buf_load_v4i_s(rs, coef_voff, 2u * half_step);
-        }
         RefRows rf = rfh[half], rb = rbh[half];
 
-        // ---- stage 1: coefficient rows -> LDS tile [r][b][c] ------------------------------
-        *reinterpret_cast<v4i*>(lds_wr) = cv;                 // sparse: cv == 0 clears the tile
+        // ---- stage 1: the LDS tile [r][b][c] -----------------------------------------------------
+        // dense: this half's coefficient rows were requested half a task ago (coef_rows_to_lds) and have landed
+        // (waited for in front of the reference fetches / the previous half's stores); sparse: clear the tile
+        if constexpr (SPARSE) {
+            *reinterpret_cast<v4i*>(lds_wr) = v4i{0, 0, 0, 0};
+        } else if (TYPE == 1 && half == 0) {
+            wait_vmem_all();                                  // I pictures: no reference fetch in front of which to wait
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -713,6 +789,14 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         int X[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) X[i] = *reinterpret_cast<const short*>(lds_col + i * 128);
+        if constexpr (!SPARSE) {
+            if (half == 0) {
+                // the tile is in registers: the next half's rows may land in it (waited for in front of this half's stores)
+                wait_lds_all();
+                __builtin_amdgcn_wave_barrier();
+                coef_rows_to_lds(pd.coef[CHROMA ? 2 : (alpha ? 3 : 0)], lds, coef_voff, 2u * half_step);
+            }
+        }
         uint64_t nz[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) nz[i] = lanes_nonzero(X[i]);
@@ -814,6 +898,9 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             t[6] += pred_x256<2>(pred.y);
             t[7] += pred_x256<3>(pred.y);
         }
+        // everything this wave has requested is here by now -- the next half's coefficient rows in particular, so
+        // that no later wait has to count this half's stores
+        if constexpr (!SPARSE) wait_vmem_all();
         v2u o;
         o.x = sat_pk2(t[0], t[1], 8) | (sat_pk2(t[2], t[3], 8) << 16);
         o.y = sat_pk2(t[4], t[5], 8) | (sat_pk2(t[6], t[7], 8) << 16);
@@ -831,59 +918,21 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
                 // yuva, A part: the samples wait for the Y part of the same macroblocks
                 *reinterpret_cast<v2u*>(dsp.apark + half * 512 + hi3 * 64 + lo3 * 8) = o;
             } else {
-                // converted after both halves (stage 5): the upper half's rows wait behind the stash, the
-                // lower half's in the coefficient tile, which is free by then
-                *reinterpret_cast<v2u*>((half == 0 ? dsp.stash + kLdsStash : lds) + hi3 * 64 + lo3 * 8) = o;
+                // converted right away (stage 5): the rows change lanes through the hand-off strip, free since the
+                // row pass read it (the coefficient tile is already receiving the next half's rows)
+                *reinterpret_cast<v2u*>(lds + kLdsCoef + hi3 * 64 + lo3 * 8) = o;
             }
         }
         // the next half overwrites the LDS strip: order its writes behind this half's reads
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
-    if constexpr (DISPLAY && !CHROMA && AMODE != 1) {
-        // ---- stage 5 (fused display conversion): RGBA of the 64 x 16 strip ---------------------------
-        // Done after both halves: nothing of the reconstruction is live any more (in place after each half
-        // the conversion's fp64 temporaries came on top of the next half's prefetched reference rows and cost
-        // the B path two waves of occupancy).  A lane holds samples 8b .. 8b+7 of row n of each half;
-        // converted as they lie, a store instruction would write 16-byte pieces 32 bytes apart (half-filled
-        // lines).  So the rows went through LDS (written at the end of each half, ordered by the fences
-        // there) and lane (n, b) converts pixels 4b .. 4b+3 and 32+4b .. 32+4b+3: every store instruction
-        // writes one full 128-byte line per row.
-        const int xa = 64 * g + 4 * lo3;                           // first pixel of the lane's left quad
-        const __amdgpu_buffer_rsrc_t rrs = buf_rsrc(pd.rgba);
-#pragma unroll
-        for (int half = 0; half < 2; half++) {
-            const int yrow = 8 * (2 * Rt + half) + hi3;
-            // chroma: row y>>1 = stash row 4*half + (n>>1); the quad's two chroma samples start at column
-            // xa/2 of the plane = 32*side + 2b within the chroma group; the right quad 16 columns further
-            const char* yp = (half == 0 ? dsp.stash + kLdsStash : lds) + hi3 * 64 + lo3 * 4;
-            const char* sp = dsp.stash + (4 * half + (hi3 >> 1)) * 64 + 32 * dsp.side + 2 * lo3;
-            const uint32_t ya = *reinterpret_cast<const uint32_t*>(yp), yb = *reinterpret_cast<const uint32_t*>(yp + 32);
-            const uint32_t cba = *reinterpret_cast<const uint16_t*>(sp), cra = *reinterpret_cast<const uint16_t*>(sp + 512);
-            const uint32_t cbb = *reinterpret_cast<const uint16_t*>(sp + 16), crb = *reinterpret_cast<const uint16_t*>(sp + 528);
-            uint32_t aa = 0xffffffffu, ab = 0xffffffffu;           // yuva: the pixels' A samples, parked by the A part
-            if constexpr (AMODE == 2) {
-                const char* ap = dsp.apark + half * 512 + hi3 * 64 + lo3 * 4;
-                aa = *reinterpret_cast<const uint32_t*>(ap);
-                ab = *reinterpret_cast<const uint32_t*>(ap + 32);
-            }
-            // the frame is the top-left crop of the coded picture; its width is a multiple of 8 (host check)
-            const uint32_t row_off = (uint32_t)yrow * (uint32_t)G.fw;
-            const bool in_a = yrow < G.fh && xa < G.fw, in_b = yrow < G.fh && xa + 32 < G.fw;
-            // one quad after the other
-            __builtin_amdgcn_sched_barrier(0);
-            const v4u pa = rgba_row4(ya, cba, cra, aa);
-            __builtin_amdgcn_raw_buffer_store_b128(pa, rrs, (int)(((row_off + (uint32_t)xa) * 4u) | (in_a ? 0u : kOobBit)), 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-            const v4u pb = rgba_row4(yb, cbb, crb, ab);
-            __builtin_amdgcn_raw_buffer_store_b128(pb, rrs, (int)(((row_off + (uint32_t)xa + 32u) * 4u) | (in_b ? 0u : kOobBit)), 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
+        if constexpr (DISPLAY && !CHROMA && AMODE != 1) {
+            display_half<AMODE>(pd, G, dsp, lds + kLdsCoef, half, Rt, g, hi3, lo3);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
-        // the next part of the task reuses the strip
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
@@ -947,12 +996,26 @@ __global__ __launch_bounds__(kReconMaxThreads) void k_recon_display(const PicDes
     const int wg = xcd_remap(blockIdx.x, G.n_wg);
     const int pic = div_inv(wg, G.inv_wg_per_pic);
     const int t = (wg - pic * G.wg_per_pic) * kWavesPerWG + wave;
-    if (t >= G.tasks_per_pic) return;
+    // the conversion tables: 5 KB per workgroup, requested before anything else and needed only after the
+    // chroma part -- the barrier below finds them long landed.  Every wave takes part, with or without a task.
+    __shared__ __attribute__((aligned(16))) int32_t lut_s[kLdsLut / 4];      // static: its LDS address is a compile-time constant
+    {
+        const int32_t LEON_GLOBAL* src = gptr(T->rgba_lut);
+        int32_t* dst = lut_s;
+        int32_t v[5];
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] = src[threadIdx.x + 256 * k];
+#pragma unroll
+        for (int k = 0; k < 5; k++) dst[threadIdx.x + 256 * k] = v[k];
+    }
+    const bool live = t < G.tasks_per_pic;
     char* lds = smem + wave * (ALPHA ? kLdsPerWaveDisplayAlpha : kLdsPerWaveDisplay);
-    const PicDesc& pd = descs[pic];
+    const PicDesc& pd = descs[live ? pic : 0];
     const int Rt = div_inv(t, G.inv_gC), gc = t - Rt * G.gC;
-    Display dsp{lds + kLdsPerWave, 0, lds + kLdsPerWaveDisplay};
-    recon_task<TYPE, true, SPARSE, true>(pd, G, T, Rt, gc, lds, lane, dsp);
+    Display dsp{lds + kLdsPerWave, 0, lds + kLdsPerWaveDisplay, reinterpret_cast<const char*>(lut_s)};
+    if (live) recon_task<TYPE, true, SPARSE, true>(pd, G, T, Rt, gc, lds, lane, dsp);
+    __syncthreads();
+    if (!live) return;
     // the two luma parts as two calls, not a loop: the loop form keeps 15 more registers live (B path: 93).
     // yuva: the A part of the same four macroblocks first (AMODE 1), then the Y part that displays them (AMODE 2).
     dsp.side = 0;

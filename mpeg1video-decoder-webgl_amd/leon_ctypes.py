@@ -111,10 +111,11 @@ def load():
             import torch  # noqa: F401
         except Exception:
             pass
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("LEON_DEBUG_LIB") or LIB_PATH      # A/B runs of kernel variants (tools/ab_bench.sh)
+    if not os.path.exists(path):
         raise ImportError("libleon_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C mpeg1video-decoder-webgl_amd/csrc` (no CPU fallback exists)")
-    lib = C.CDLL(LIB_PATH)
+    lib = C.CDLL(path)
     lib.leon_last_error.restype = C.c_char_p
     lib.leon_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
     lib.leon_destroy.argtypes = [C.c_void_p]

@@ -101,6 +101,50 @@ def test_fused_gop_equals_oracle(L, O, S, size, sparse):
         dec.close()
 
 
+def test_fused_conversion_of_every_y_cb_cr(L, O, S):
+    """all 2^24 (Y, Cb, Cr) through the fused kernel's table conversion (leon_rgba_lut.h): a 4096 x 4096 P picture
+    without residual and with zero vectors hands the planes written into its reference slot to stage 5; the 2x2
+    quads run through all (Cb, Cr), the samples of the 64 quads that share a pair through all Y"""
+    import torch
+    import leon_vlc_ctypes as V
+    n = 4096
+    q = np.arange(n // 2)
+    qy, qx = np.meshgrid(q, q, indexing="ij")
+    cb = (qx & 255).astype(np.uint8)
+    cr = (qy & 255).astype(np.uint8)
+    k = ((qx >> 8) + 8 * (qy >> 8)).astype(np.int64)                       # 0..63: which of the 64 quads of its (Cb, Cr)
+    y = np.empty((n, n), np.uint8)
+    for dy in range(2):
+        for dx in range(2):
+            y[dy::2, dx::2] = 4 * k + 2 * dy + dx
+    seen = np.zeros((256, 256, 256), bool)
+    seen[y.reshape(n // 2, 2, n // 2, 2), cb[:, None, :, None], cr[:, None, :, None]] = True
+    assert seen.all()
+    mbs = (n // 16) ** 2
+    zeros = np.zeros((n, n), np.int16)
+    go, en = V.sparsify(zeros, zeros[:n // 2, :n // 2], zeros[:n // 2, :n // 2], n, n)
+    assert len(en) == 0
+    dec = L.Decoder(n, n, n_slots=2)
+    try:
+        dec.write_planes(0, y, cb, cr)
+        rgba = torch.zeros((n, n, 4), dtype=torch.uint8, device="cuda")
+        keep = []
+        pic = L.make_sparse_picture(S.PIC_P, 1, go, np.zeros(1, np.uint32), 0, np.ones(mbs, np.uint8), np.zeros(mbs, np.uint8),
+                                    repadd=np.zeros(mbs, np.uint8), mv_fwd=np.zeros((mbs, 2), np.int16), ref_fwd_slot=0, keep=keep,
+                                    rgba_out=rgba.data_ptr())
+        dec.submit_sparse([pic], L.MEM_HOST)
+        dec.sync()
+        assert np.array_equal(planes_flat(*dec.read_planes(1)), planes_flat(y, cb, cr))
+        want = O.ycbcr_to_rgba(y, cb, cr, n, n, n, "cpu").reshape(n, n, 4)
+        got = rgba.cpu().numpy()
+        bad = np.argwhere(got != want)
+        assert bad.size == 0, "%d bytes differ, first at %s: Y %d Cb %d Cr %d -> %s, oracle %s" % (
+            len(bad), bad[0], y[bad[0][0], bad[0][1]], cb[bad[0][0] // 2, bad[0][1] // 2], cr[bad[0][0] // 2, bad[0][1] // 2],
+            got[bad[0][0], bad[0][1]], want[bad[0][0], bad[0][1]])
+    finally:
+        dec.close()
+
+
 def test_fused_batch_mixed_with_plain_pictures(L, O, S):
     """one device batch holding fused and plain pictures of the same type: two launch classes"""
     import torch

@@ -17,7 +17,7 @@ HIPCC = "/opt/rocm/bin/hipcc"
 BUDGET = {
     "k_reconILi1ELb0E": 64, "k_reconILi2ELb0E": 64, "k_reconILi3ELb0E": 72,
     "k_reconILi1ELb1E": 64, "k_reconILi2ELb1E": 64, "k_reconILi3ELb1E": 72,
-    "k_recon_displayILi1ELb0ELb0E": 64, "k_recon_displayILi2ELb0ELb0E": 64, "k_recon_displayILi3ELb0ELb0E": 80,
+    "k_recon_displayILi1ELb0ELb0E": 64, "k_recon_displayILi2ELb0ELb0E": 64, "k_recon_displayILi3ELb0ELb0E": 72,
     "k_recon_displayILi1ELb1ELb0E": 64, "k_recon_displayILi2ELb1ELb0E": 64, "k_recon_displayILi3ELb1ELb0E": 80,
     # yuva (A part + Y part per side): one occupancy step below the three-component kernels
     "k_recon_displayILi1ELb0ELb1E": 64, "k_recon_displayILi2ELb0ELb1E": 72, "k_recon_displayILi3ELb0ELb1E": 88,
