@@ -96,6 +96,10 @@ struct Tables {
     // lookup on the next 12 bits: bits 0..6 length (sign included), bit 7 = end of block ('10'),
     // bits 8..15 run, bits 16..31 the signed level.  0 = longer code or escape: the general path.  16 KB.
     uint32_t fast12[4096];
+    // The same for the FIRST symbol of a block, where '1s' is run 0, level +-1 and no end of block exists.
+    uint32_t first12[4096];
+    // motion_code with its sign bit in one lookup on 11 bits: (len << 16) | (code + 16); 0 = invalid
+    int32_t motion_s[2048];
     Tables()
     {
         mba.init(11);
@@ -116,6 +120,16 @@ struct Tables {
         for (int i = 1; i < 64; i++) cbp.add(i, kCbp[i].code, kCbp[i].len);
         motion.init(10);
         for (int i = 0; i < 17; i++) motion.add(i, kMotion[i].code, kMotion[i].len);
+        for (unsigned p = 0; p < 2048; p++) {
+            const int32_t e = motion.t[p >> 1];                    // the 10-bit table of the unsigned codes
+            int32_t m = 0;
+            if (e != 0) {
+                const int len = e >> 16, code = e & 0xffff;
+                if (code == 0) m = (len << 16) | 16;               // '1': no sign bit follows
+                else m = ((len + 1) << 16) | (((p >> (10 - len)) & 1) ? 16 - code : 16 + code);
+            }
+            motion_s[p] = m;
+        }
         dc_lum.init(7);
         const int dl[9][2] = {{0x4, 3}, {0x0, 2}, {0x1, 2}, {0x5, 3}, {0x6, 3}, {0xe, 4}, {0x1e, 5}, {0x3e, 6}, {0x7e, 7}};
         for (int i = 0; i < 9; i++) dc_lum.add(i, (unsigned)dl[i][0], dl[i][1]);
@@ -154,6 +168,7 @@ struct Tables {
                 }
             }
             fast12[p] = f;
+            first12[p] = (p >> 11) ? ((uint32_t)(uint16_t)(int16_t)(((p >> 10) & 1) ? -1 : 1) << 16) | 2u : f;
         }
     }
 };
@@ -213,6 +228,52 @@ struct Bits {
     }
 };
 
+// The slice decoder's view of the stream: a 64-bit window `w` that holds the bits from `pos` on, left aligned,
+// `avail` of them valid; reloaded (8 bytes, byte swapped) only when a caller needs more than are left.  Every
+// syntax element below the slice header -- macroblock header, vectors, DC sizes, coefficients -- is read from it
+// with shifts and one table lookup; nothing recomputes a byte address per element.
+struct Win {
+    const uint8_t* b = nullptr;
+    size_t nbytes = 0;           // real length (the buffer has 16 readable bytes more, all zero)
+    size_t pos = 0;              // in bits
+    uint64_t w = 0;
+    int avail = 0;
+    bool bad = false;
+
+    void refill()
+    {
+        if ((pos >> 3) >= nbytes) { bad = true; w = 0; avail = 64; return; }       // zeros: no table loops on them
+        memcpy(&w, b + (pos >> 3), 8);
+        w = __builtin_bswap64(w) << (pos & 7);
+        avail = 64 - (int)(pos & 7);
+    }
+    void need(int n) { if (avail < n) refill(); }            // n <= 57
+    uint32_t peek(int n) const { return (uint32_t)(w >> (64 - n)); }      // 1 <= n <= 32, after need(n)
+    void drop(int n) { w <<= n; avail -= n; pos += (size_t)n; }
+    uint32_t get(int n)          // n <= 32
+    {
+        if (n == 0) return 0;
+        need(n);
+        const uint32_t v = peek(n);
+        drop(n);
+        return v;
+    }
+    int vlc(const Lookup& t)     // max_len <= 16
+    {
+        need(t.max_len);
+        const int32_t e = t.t[peek(t.max_len)];
+        if (e == 0) { bad = true; return 0; }
+        drop(e >> 16);
+        return e & 0xffff;
+    }
+    bool next_bits_are_start_code() const      // decoders/jsv.js:1710-1760
+    {
+        const size_t i = (pos + 7) >> 3;
+        if (i + 2 >= nbytes) return true;
+        return b[i] == 0 && b[i + 1] == 0 && b[i + 2] == 1;
+    }
+};
+
 enum { START_PICTURE = 0x00, START_SLICE_FIRST = 0x01, START_SLICE_LAST = 0xAF, START_USER_DATA = 0xB2,
        START_SEQUENCE_ES = 0xB3, START_SEQUENCE = 0xC3, START_EXTENSION = 0xB5, START_GOP = 0xB8, START_MAP = 0xC4 };
 
@@ -223,7 +284,8 @@ struct SliceJob { int code; size_t bitpos; };
 // plus the entry count per group.  No sort is needed afterwards -- the streams are concatenated.
 struct RowRun {                             // streams: 0/1 luma block rows, 2 Cb, 3 Cr, 4/5 the A plane's block rows (yuva)
     int mb_row = 0;
-    std::vector<uint32_t> ent[6];
+    std::vector<uint32_t> ent[6];              // sized ahead of `used` (a block appends up to 64 entries through a raw pointer)
+    size_t used[6] = {0, 0, 0, 0, 0, 0};
     std::vector<uint32_t> cnt[6];
 };
 struct alignas(128) SliceOut {             // one per slice; written by exactly one worker
@@ -293,10 +355,10 @@ namespace {
 struct SliceCtx {
     const Tables* T = &tables();      // looked up once per slice: the function-local static's guard showed up in the profile
     leon_vlc_stream* s;
-    Bits r;
+    Win r;
     SliceOut* sout;
     RowRun* run = nullptr;
-    int mb_addr = 0, mb_row = 0, mb_col = 0;
+    int mb_addr = 0, mb_row = 0, mb_col = 0, rc_addr = 0;      // (mb_row, mb_col) = position of address rc_addr
     bool slice_begin = true;
     int fw_h = 0, fw_v = 0, fw_h_prev = 0, fw_v_prev = 0, bw_h = 0, bw_v = 0, bw_h_prev = 0, bw_v_prev = 0, prev_dir = 0;
     int dc_y = 128, dc_cr = 128, dc_cb = 128, dc_a = 128, qs = 0;
@@ -306,11 +368,16 @@ struct SliceCtx {
 
 int motion_component(SliceCtx& c, int prev, int rsize, int f)
 {
-    Bits& r = c.r;
-    int code = r.vlc(c.T->motion), d;
-    if (code != 0 && r.get(1)) code = -code;
+    Win& r = c.r;
+    r.need(11 + 8);                                            // code, sign and the residual (r_size <= 6) in one window
+    const int32_t e = c.T->motion_s[r.peek(11)];
+    if (e == 0) { r.bad = true; return prev; }
+    r.drop(e >> 16);
+    int code = (e & 0xffff) - 16, d;
     if (code != 0 && f != 1) {
-        d = (((code < 0 ? -code : code) - 1) << rsize) + (int)r.get(rsize) + 1;
+        const int res = (int)r.peek(rsize);                    // rsize >= 1 here
+        r.drop(rsize);
+        d = (((code < 0 ? -code : code) - 1) << rsize) + res + 1;
         if (code < 0) d = -d;
     } else d = code;
     prev += d;
@@ -343,7 +410,7 @@ void decode_motion_vectors(SliceCtx& c)
 // decoders/jsv.js:1338-1525 (decodeBlockGL): raw levels, emitted as sparse entries
 bool decode_block(SliceCtx& c, int block)
 {
-    Bits& r = c.r;
+    Win& r = c.r;
     const Tables& T = *c.T;
     // stream of the current row run and group inside the row
     int stream;
@@ -360,7 +427,13 @@ bool decode_block(SliceCtx& c, int block)
         bq = (uint32_t)(c.mb_col & 7);
     }
     const uint32_t boff = (bq * 16u) << 16;
-    int n = 0, c_dc_pending = 0;
+    // entries go straight to the end of the run's stream: room for a whole block is made first
+    RowRun& run = *c.run;
+    std::vector<uint32_t>& ev = run.ent[stream];
+    const size_t used = run.used[stream];
+    if (ev.size() < used + 64) ev.resize(std::max(ev.size() * 2, used + 64 + 960));
+    uint32_t* const out = ev.data() + used;
+    int k = 0, n = 0;
     if (c.mb_intra) {
         int predictor, size;
         if (block < 4) { predictor = c.dc_y; size = r.vlc(T.dc_lum); }
@@ -373,89 +446,76 @@ bool decode_block(SliceCtx& c, int block)
                                                     : predictor + ((int)(0xffffffffu << size) | (differential + 1));
         }
         if (block < 4) c.dc_y = dc; else if (block >= 6) c.dc_a = dc; else if (block == 4) c.dc_cr = dc; else c.dc_cb = dc;
-        c_dc_pending = dc;
+        if ((int16_t)dc != 0) out[k++] = boff | (uint16_t)(int16_t)dc;
         n = 1;
     }
-    // The coefficient loop works on a 64-bit window of the stream (>= 57 valid bits; one symbol takes
-    // at most 28) and reads code, sign and escape fields out of it with shifts: one table lookup and
-    // one position update per coefficient.  Same decisions as the reference's loop, jsv.js:1396-1443.
-    const uint8_t* const bytes = r.b;
-    const size_t end_bits = r.nbytes * 8;
+    // The coefficient loop: one table lookup and one window update per coefficient (a symbol takes at most
+    // 28 bits).  Same decisions as the reference's loop, jsv.js:1396-1443.  The window lives in locals here (the
+    // entry stores could alias the struct's fields as far as the compiler knows) and goes back at every exit.
+    const uint32_t* fast = n > 0 ? T.fast12 : T.first12;       // the first symbol of a block has no end-of-block code
+    uint64_t w = r.w;
+    int avail = r.avail;
     size_t pos = r.pos;
-    uint32_t tmp[64];
-    int k = 0;
-    if (c.mb_intra && (int16_t)c_dc_pending != 0) tmp[k++] = boff | (uint16_t)(int16_t)c_dc_pending;
-    // Bit window: `w` holds the stream from `pos` on, left aligned, `avail` of its bits valid.  It is
-    // reloaded (8 bytes, byte swapped) only when fewer than 28 valid bits are left -- the longest symbol.
-    uint64_t w = 0;
-    int avail = 0;
+    const uint8_t* const bytes = r.b;
+    const size_t end_byte = r.nbytes;
+#define LEON_WIN_BACK() do { r.w = w; r.avail = avail; r.pos = pos; } while (0)
     for (;;) {
         if (avail < 28) {
-            if (pos >= end_bits) { r.pos = pos; r.bad = true; c.err = "bitstream ends inside a block"; return false; }
+            if ((pos >> 3) >= end_byte) { LEON_WIN_BACK(); r.bad = true; c.err = "bitstream ends inside a block"; return false; }
             memcpy(&w, bytes + (pos >> 3), 8);
             w = __builtin_bswap64(w) << (pos & 7);
             avail = 64 - (int)(pos & 7);
         }
-        if (n > 0) {                                          // every symbol but a block's first: one lookup
-            const uint32_t f = T.fast12[w >> 52];
-            const int flen = (int)(f & 0x7fu);
-            if (f & 0x80u) { pos += 2; break; }               // end of block
-            if (flen) {
-                n += (int)((f >> 8) & 0xffu);
-                if (n > 63) { r.pos = pos + (size_t)flen; c.err = "coefficient index overflow"; return false; }
-                const uint32_t z = kZigZag[n++];
-                tmp[k++] = boff | (((z >> 3) * 128u + (z & 7u) * 2u) << 16) | (f >> 16);
-                // (resolving the FOLLOWING symbol from the same 12 bits as well -- a second table -- was measured on
-                // the GPU box's EPYC 9575F: 890-900 pictures/s per thread against 900-910 without; not kept)
-                pos += (size_t)flen;
-                w <<= flen;
-                avail -= flen;
-                continue;
-            }
+        const uint32_t f = fast[w >> 52];
+        const int flen = (int)(f & 0x7fu);
+        if (flen) {
+            w <<= flen;
+            avail -= flen;
+            pos += (size_t)flen;
+            if (f & 0x80u) break;                             // end of block
+            n += (int)((f >> 8) & 0xffu);
+            if (n > 63) { LEON_WIN_BACK(); c.err = "coefficient index overflow"; return false; }
+            const uint32_t z = kZigZag[n++];
+            out[k++] = boff | (((z >> 3) * 128u + (z & 7u) * 2u) << 16) | (f >> 16);
+            // (resolving the FOLLOWING symbol from the same 12 bits as well -- a second table -- was measured on
+            // the GPU box's EPYC 9575F: 890-900 pictures/s per thread against 900-910 without; not kept)
+            fast = T.fast12;
+            continue;
         }
+        // longer codes and escapes ('1...' never gets here: both tables resolve it)
         int32_t e = T.coef8[w >> 56];
         if (e == 0) {
             e = T.coef.t[w >> 48];
-            if (e == 0) { r.pos = pos; r.bad = true; c.err = "invalid coefficient code"; return false; }
+            if (e == 0) { LEON_WIN_BACK(); r.bad = true; c.err = "invalid coefficient code"; return false; }
         }
         const int len = e >> 16, coeff = e & 0xffff;
-        const size_t pos0 = pos;
-        int run, level;
-        if (coeff == 0x0001) {                               // the one-bit code '1'
-            if (n > 0) {
-                if (((w >> 62) & 1) == 0) { pos += 2; break; }          // '10' = end of block
-                level = ((w >> 61) & 1) ? -1 : 1;                       // '11' + sign
-                pos += 3;
-            } else {
-                level = ((w >> 62) & 1) ? -1 : 1;                       // first coefficient: '1' + sign
-                pos += 2;
-            }
-            run = 0;
-        } else if (coeff == 0xffff) {                        // escape: 6-bit run, 8- or 16-bit level
-            run = (int)((w >> 52) & 63);
+        int run_len, level, used_bits;
+        if (coeff == 0xffff) {                               // escape: 6-bit run, 8- or 16-bit level
+            run_len = (int)((w >> 52) & 63);
             level = (int)((w >> 44) & 255);
-            pos += 20;
-            if (level == 0) { level = (int)((w >> 36) & 255); pos += 8; }
-            else if (level == 128) { level = (int)((w >> 36) & 255) - 256; pos += 8; }
+            used_bits = 20;
+            if (level == 0) { level = (int)((w >> 36) & 255); used_bits = 28; }
+            else if (level == 128) { level = (int)((w >> 36) & 255) - 256; used_bits = 28; }
             else if (level > 128) level -= 256;
         } else {
-            run = coeff >> 8;
+            run_len = coeff >> 8;
             level = coeff & 0xff;
             if ((w >> (63 - len)) & 1) level = -level;
-            pos += (size_t)len + 1;
+            used_bits = len + 1;
         }
-        w <<= (pos - pos0);
-        avail -= (int)(pos - pos0);
-        n += run;
-        if (n > 63) { r.pos = pos; c.err = "coefficient index overflow"; return false; }
+        w <<= used_bits;
+        avail -= used_bits;
+        pos += (size_t)used_bits;
+        fast = T.fast12;
+        n += run_len;
+        if (n > 63) { LEON_WIN_BACK(); c.err = "coefficient index overflow"; return false; }
         const uint32_t z = kZigZag[n++];
-        if (level != 0) tmp[k++] = boff | (((z >> 3) * 128u + (z & 7u) * 2u) << 16) | (uint16_t)(int16_t)level;
+        if (level != 0) out[k++] = boff | (((z >> 3) * 128u + (z & 7u) * 2u) << 16) | (uint16_t)(int16_t)level;
     }
-    r.pos = pos;
-    if (k) {
-        c.run->ent[stream].insert(c.run->ent[stream].end(), tmp, tmp + k);
-        c.run->cnt[stream][grow] += (uint32_t)k;
-    }
+    LEON_WIN_BACK();
+#undef LEON_WIN_BACK
+    run.used[stream] = used + (size_t)k;
+    run.cnt[stream][grow] += (uint32_t)k;
     return !r.bad;
 }
 
@@ -464,7 +524,7 @@ bool decode_block(SliceCtx& c, int block)
 int decode_macroblock(SliceCtx& c)
 {
     leon_vlc_stream* s = c.s;
-    Bits& r = c.r;
+    Win& r = c.r;
     const Tables& T = *c.T;
     const int type = s->type;
     int increment = 0, t = r.vlc(T.mba);
@@ -496,15 +556,17 @@ int decode_macroblock(SliceCtx& c)
     }
     const int mb = c.mb_addr;
     if (mb < 0 || mb >= s->mbsize) { c.err = "macroblock address outside the picture"; return 0; }
-    c.mb_row = mb / s->mbw;
-    c.mb_col = mb % s->mbw;
+    // row and column follow the address without a division (addresses only grow inside a slice)
+    c.mb_col += mb - c.rc_addr;
+    c.rc_addr = mb;
+    while (c.mb_col >= s->mbw) { c.mb_col -= s->mbw; c.mb_row++; }
     if (!c.run || c.run->mb_row != c.mb_row) {
         SliceOut& so = *c.sout;
         if (so.used == so.runs.size()) so.runs.emplace_back();
         c.run = &so.runs[so.used++];
         c.run->mb_row = c.mb_row;
         for (int k = 0; k < s->n_streams; k++) {
-            c.run->ent[k].clear();
+            c.run->used[k] = 0;
             c.run->cnt[k].assign((size_t)(k == 2 || k == 3 ? s->gc : s->gy), 0u);
         }
     }
@@ -553,14 +615,17 @@ void decode_slice(leon_vlc_stream* s, const SliceJob& job, SliceOut* out)
 {
     SliceCtx c;
     c.s = s;
-    c.r = s->r;
+    c.r.b = s->r.b;
+    c.r.nbytes = s->r.nbytes;
     c.r.pos = job.bitpos;
-    c.r.bad = false;
     c.sout = out;
     out->used = 0;
     c.mb_addr = (job.code - 1) * s->mbw - 1;
+    c.mb_row = job.code - 1;
+    c.mb_col = -1;
+    c.rc_addr = c.mb_addr;
     c.qs = (int)c.r.get(5);
-    while (c.r.get(1) && !c.r.bad) c.r.skip(8);
+    while (c.r.get(1) && !c.r.bad) c.r.get(8);
     do {
         if (decode_macroblock(c) == 0) break;
     } while (!c.r.next_bits_are_start_code() && !c.r.bad);
