@@ -46,6 +46,12 @@ typedef struct leon_pipeline_config {
      * host seeks by destroying it and creating one at the new time, as the reference frees all its output
      * buffers on a seek, jsv.js:1623.) */
     double start_seconds;
+    /* != 0: the slice layer (everything below a slice start code: macroblock headers, vectors, coefficients --
+     * decodeSlice .. decodeBlockGL, decoders/jsv.js:683-1525) is decoded on the GPU, one lane per slice
+     * (csrc/leon_vlc_gpu.h); the parser threads only read the picture layer and upload the stream bytes.  Same
+     * frames; errors of a slice surface when its window completes.  0: on the parser threads (libleon_vlc.so). */
+    int32_t gpu_parser;
+    int32_t reserved;
 } leon_pipeline_config;
 
 /* One decoded picture.  rgba stays valid until leon_pipeline_release_window(window) */

@@ -109,6 +109,39 @@ int leon_vlc_next_picture(leon_vlc_stream* s, leon_vlc_picture* out);
  * until the next call.  Not to be mixed with leon_vlc_next_picture on one stream. */
 int leon_vlc_next_picture_sync(leon_vlc_stream* s, leon_vlc_picture* out);
 
+/* The picture layer only (decodePicture's header part, decoders/jsv.js:583-650, and the slice start codes
+ * :651-660): the next picture's header fields and where its slices start, nothing below the slice start code is
+ * read.  For a front end that decodes the slices elsewhere -- the GPU parser of the pipeline
+ * (leon_pipeline_config.gpu_parser).  Positions are relative to the bytes given to leon_vlc_open*; the arrays
+ * stay valid until the next call.  Not to be mixed with leon_vlc_next_picture* on one stream. */
+typedef struct leon_vlc_picture_scan {
+    int32_t type, temporal_reference;
+    double  ts_ms;
+    int32_t new_sequence;
+    int32_t full_pel_fwd, fwd_rsize;     /* forward_f = 1 << fwd_rsize (jsv.js:607-613) */
+    int32_t full_pel_bwd, bwd_rsize;
+    uint32_t n_slices;
+    const int32_t* slice_code;           /* [n_slices] slice_vertical_position, 1 .. 175 */
+    const uint64_t* slice_bit_pos;       /* [n_slices] first bit behind the slice start code */
+    uint64_t end_byte;                   /* the first byte behind the picture's last slice (next start code, or the end) */
+} leon_vlc_picture_scan;
+int leon_vlc_scan_picture(leon_vlc_stream* s, leon_vlc_picture_scan* out);
+
+/* The front end's decoding tables as plain arrays (entries as in leon_vlc.cpp's Tables: (length << 16) | value,
+ * 0 = invalid code), for a slice decoder that runs elsewhere: mpeg1video-decoder-webgl_amd/csrc/leon_vlc_gpu.h. */
+typedef struct leon_vlc_gpu_tables {
+    uint32_t fast12[4096];       /* a coefficient symbol (not a block's first) from its next 12 bits: bits 0..6 length,
+                                    bit 7 end of block, bits 8..15 run, bits 16..31 level; 0 = longer code or escape */
+    int32_t  coef16[65536];      /* any coefficient code without its sign bit, by the next 16 bits */
+    int32_t  motion_s[2048];     /* motion_code with its sign: (len << 16) | (code + 16) */
+    int32_t  mba[2048];          /* macroblock_address_increment; 34 = stuffing, 35 = escape */
+    int32_t  mbtype[4][64];      /* [picture type][next 6 bits] -> flags 0x10 quant | 0x08 fwd | 0x04 bwd | 0x02 pattern | 0x01 intra */
+    int32_t  cbp[512];
+    int32_t  dc_lum[128], dc_chr[256];
+    uint16_t zz_off[64];         /* tile byte offset r*128 + c*2 of zig-zag index n */
+} leon_vlc_gpu_tables;
+int leon_vlc_get_gpu_tables(leon_vlc_gpu_tables* out);
+
 /* = jsv.prototype.seek (decoders/jsv.js:1618-1648): position on the key-map entry at or before
  * `seconds`; decoding resumes at the next sequence header.  *byte_offset receives the offset. */
 int leon_vlc_seek(leon_vlc_stream* s, double seconds, uint64_t* byte_offset);
@@ -116,8 +149,11 @@ int leon_vlc_seek(leon_vlc_stream* s, double seconds, uint64_t* byte_offset);
 /* The GOP key map of the container header (decoders/jsv.js:264-268, :282-313): absolute byte offset
  * of each GOP's sequence header and its time code.  Fills at most `capacity` entries (either array
  * may be NULL) and returns the number of entries the stream has.  A stream opened on the bytes from
- * one entry's offset up to the next one's (a "GOP shard": it starts with 00 00 01 C3) decodes
- * exactly that GOP -- the unit of the frame-parallel partition. */
+ * one entry's offset up to the next one's PLUS THREE (a "GOP shard": it starts with 00 00 01 C3 and ends
+ * with the 00 00 01 of what follows, without the code byte) decodes exactly that GOP -- the unit of the
+ * frame-parallel partition.  The three bytes matter: the slice loop ends a slice at a start
+ * code prefix or within two bytes of the end of the data (jsv.js:1710-1760); cut at the offset itself, a
+ * last macroblock of two bytes or less would be taken for that end and dropped. */
 int leon_vlc_get_keymap(leon_vlc_stream* s, uint32_t* byte_offsets, uint32_t* timecodes, uint32_t capacity);
 
 /* sparse lists -> the dense int16 planes the reference uploads (planes are overwritten) */

@@ -2,6 +2,7 @@
 // (it uses the decoder's internals: submit_batch_any, the slot ring, the decoder's stream).
 #include "../../include/leon_pipeline.h"
 #include "../../include/leon_vlc.h"
+#include "leon_vlc_gpu.h"
 
 #include <atomic>
 #include <chrono>
@@ -25,7 +26,7 @@ struct PipePic {                 // one parsed picture: offsets of its arrays in
 struct Arena {                   // pinned host buffer + its device twin, one GOP at a time
     char* host = nullptr;
     char* dev = nullptr;
-    size_t cap = 0, used = 0;
+    size_t cap = 0, host_cap = 0, used = 0;      // cap: of the device twin
 };
 
 struct GopJob {
@@ -36,6 +37,12 @@ struct GopJob {
     double gop_ts_ms = 0;
     int status = LEON_OK;
     std::string err;
+    // gpu_parser: the slices of the GOP and its pictures as the device kernels want them (pointers into the arena's
+    // device twin; VlcSlice::pic counts inside the GOP until submit_window rebases it), what of the arena is uploaded
+    // (stream bytes) and what is cleared on the device (counters, error words, maps)
+    std::vector<leon::VlcSlice> slices;
+    std::vector<leon::VlcPic> vpics;
+    size_t upload_bytes = 0, zero_begin = 0, zero_bytes = 0;
 };
 
 struct PipeWindow {
@@ -45,6 +52,15 @@ struct PipeWindow {
     std::vector<leon_pipeline_frame> frames;
     hipEvent_t done = nullptr;
     int status = LEON_OK;
+    uint32_t n_vpics = 0;        // gpu_parser: error words of the window's pictures are in the ring entry's h_err
+};
+
+struct VlcRing {                 // gpu_parser: per ring entry, the window's slice / picture descriptors
+    char* h = nullptr;           // pinned: [VlcSlice x n][VlcPic x m]
+    char* d = nullptr;           // device: the same + [slice_words x n][error x m]
+    size_t cap = 0;
+    uint32_t* h_err = nullptr;   // pinned copy of the error words
+    size_t err_cap = 0;
 };
 
 constexpr size_t kNone = (size_t)-1;
@@ -69,6 +85,10 @@ struct leon_pipeline {
     leon_decoder* dec = nullptr;
     hipStream_t copy_stream = nullptr;
     uint8_t* d_rgba = nullptr;                        // R ring entries of W * max_pics frames
+    bool gpu_parser = false;
+    leon::VlcTables* d_vlc_tables = nullptr;
+    leon::VlcGeom vgeom{};
+    std::vector<VlcRing> vlc_ring;
 
     std::mutex mu;
     std::condition_variable cv;
@@ -106,23 +126,146 @@ void pipe_fail(leon_pipeline* p, int code, const std::string& msg)
     p->cv.notify_all();
 }
 
-bool arena_reserve(leon_pipeline* p, Arena* a, size_t need)
+// host_need bytes of pinned memory and dev_need bytes of its device twin (equal for a GOP parsed on the host: the
+// arena is copied as it is; the GPU parser uploads the stream bytes only and keeps everything else on the device)
+bool arena_reserve(leon_pipeline* p, Arena* a, size_t host_need, size_t dev_need)
 {
-    if (need <= a->cap) return true;
-    size_t cap = std::max(need + need / 2, (size_t)8 << 20);
-    char *h = nullptr, *dv = nullptr;
-    if (hipHostMalloc((void**)&h, cap, hipHostMallocDefault) != hipSuccess) return false;
-    if (hipMalloc((void**)&dv, cap) != hipSuccess) {
-        hipHostFree(h);
-        return false;
+    (void)p;
+    if (host_need > a->host_cap) {
+        const size_t cap = std::max(host_need + host_need / 2, (size_t)4 << 20);
+        char* h = nullptr;
+        if (hipHostMalloc((void**)&h, cap, hipHostMallocDefault) != hipSuccess) return false;
+        if (a->used) memcpy(h, a->host, std::min(a->used, a->host_cap));
+        if (a->host) hipHostFree(a->host);
+        a->host = h;
+        a->host_cap = cap;
     }
-    if (a->used) memcpy(h, a->host, a->used);
-    if (a->host) hipHostFree(a->host);
-    if (a->dev) hipFree(a->dev);        // only ever grown while the arena is being filled: nothing in flight reads it
-    a->host = h;
-    a->dev = dv;
-    a->cap = cap;
+    if (dev_need > a->cap) {
+        const size_t cap = std::max(dev_need + dev_need / 2, (size_t)8 << 20);
+        char* dv = nullptr;
+        if (hipMalloc((void**)&dv, cap) != hipSuccess) return false;
+        if (a->dev) hipFree(a->dev);        // only ever grown while the arena is being filled: nothing in flight reads it
+        a->dev = dv;
+        a->cap = cap;
+    }
     return true;
+}
+
+inline Arena* a_of(GopJob* job) { return job->arena; }
+
+// gpu_parser: the host reads the picture layer only (leon_vlc_scan_picture) and lays the GOP's arena out for the
+// device kernels of leon_vlc_gpu.h:
+//   [stream bytes, zero padded]                                            uploaded
+//   per picture: [error word | group counters | maps]                      cleared on the device
+//   per picture: [grp_off | entries (capacity)], per slice: [scratch]      written by the kernels
+void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const uint8_t* bytes, size_t n, uint64_t g)
+{
+    struct Scan { leon_vlc_picture_scan s; std::vector<int32_t> code; std::vector<uint64_t> pos; };
+    std::vector<Scan> scans;
+    for (;;) {
+        leon_vlc_picture_scan sc;
+        const int rc = leon_vlc_scan_picture(st, &sc);
+        if (rc == LEON_VLC_END) break;
+        if (rc != LEON_VLC_PICTURE) {
+            job->status = LEON_ERR_INVALID;
+            job->err = std::string("GOP shard ") + std::to_string(g) + ": " + leon_vlc_last_error();
+            return;
+        }
+        Scan x;
+        x.s = sc;
+        x.code.assign(sc.slice_code, sc.slice_code + sc.n_slices);
+        x.pos.assign(sc.slice_bit_pos, sc.slice_bit_pos + sc.n_slices);
+        scans.push_back(std::move(x));
+    }
+    if ((int)scans.size() > p->max_pics) {
+        job->status = LEON_ERR_INVALID;
+        job->err = "a GOP has " + std::to_string(scans.size()) + " pictures; raise max_gop_pictures (" + std::to_string(p->max_pics) + ")";
+        return;
+    }
+    if (n >= ((size_t)1 << 28)) { job->status = LEON_ERR_INVALID; job->err = "GOP shard too large for the GPU parser"; return; }
+    const size_t mbs = (size_t)p->vinfo.mb_width * p->vinfo.mb_height;
+    const size_t mpad = pad256(mbs), vpad = pad256(mbs * 4), gpad = pad256(((size_t)p->vinfo.n_groups + 1) * 4);
+    const size_t max_entries = (size_t)p->vinfo.coded_width * p->vinfo.coded_height * (p->vinfo.has_alpha == 1 ? 5 : 3) / 2;
+    const size_t stream_pad = pad256(n + 16);
+    // sizes first: the arena may move when it grows
+    const size_t zero_per_pic = 256 + gpad + 4 * mpad + 2 * vpad;
+    size_t need = stream_pad + scans.size() * zero_per_pic;
+    std::vector<size_t> ecap(scans.size());
+    std::vector<std::vector<size_t>> scap(scans.size());
+    for (size_t k = 0; k < scans.size(); k++) {
+        const Scan& x = scans[k];
+        size_t pic_words = 0;
+        scap[k].resize(x.code.size());
+        for (size_t j = 0; j < x.code.size(); j++) {
+            const uint64_t begin = x.pos[j] >> 3, end = j + 1 < x.code.size() ? (x.pos[j + 1] >> 3) - 4 : x.s.end_byte;
+            const size_t nb = end > begin ? (size_t)(end - begin) : 0;
+            scap[k][j] = 4 * nb + 72;                    // an entry takes at least two bits, a block record one word more
+            pic_words += 4 * nb;
+        }
+        ecap[k] = std::min(std::max(pic_words, (size_t)64), max_entries);
+        need += gpad + pad256(ecap[k] * 4 + 4);
+        for (size_t c : scap[k]) need += pad256(c * 4);
+    }
+    if (!arena_reserve(p, a_of(job), stream_pad, need)) { job->status = LEON_ERR_NOMEM; job->err = "staging allocation failed"; return; }
+    Arena* a = job->arena;
+    memcpy(a->host, bytes, n);
+    memset(a->host + n, 0, stream_pad - n);
+    job->upload_bytes = stream_pad;
+    size_t at = stream_pad;
+    job->zero_begin = at;
+    job->zero_bytes = scans.size() * zero_per_pic;
+    char* dev = a->dev;
+    auto take = [&](size_t bytes_) { const size_t o = at; at += bytes_; return o; };
+    for (size_t k = 0; k < scans.size(); k++) {
+        const Scan& x = scans[k];
+        PipePic m{};
+        m.type = x.s.type;
+        m.tref = x.s.temporal_reference;
+        m.ts_ms = x.s.ts_ms;
+        leon::VlcPic v{};
+        v.type = x.s.type;
+        v.full_pel_fwd = x.s.full_pel_fwd; v.fwd_rsize = x.s.fwd_rsize;
+        v.full_pel_bwd = x.s.full_pel_bwd; v.bwd_rsize = x.s.bwd_rsize;
+        v.error = (uint32_t*)(dev + take(256));
+        v.grp_cnt = (uint32_t*)(dev + take(gpad));
+        m.qscale = take(mpad); m.intra = take(mpad);
+        const size_t ra = take(mpad), md = take(mpad), mf = take(vpad), mk = take(vpad);
+        m.repadd = x.s.type != LEON_PIC_I ? ra : kNone;
+        m.mb_dir = x.s.type == LEON_PIC_B ? md : kNone;
+        m.mv_fwd = x.s.type != LEON_PIC_I ? mf : kNone;
+        m.mv_bwd = x.s.type == LEON_PIC_B ? mk : kNone;
+        v.qscale = (uint8_t*)(dev + m.qscale); v.intra = (uint8_t*)(dev + m.intra);
+        v.repadd = (uint8_t*)(dev + ra); v.mb_dir = (uint8_t*)(dev + md);
+        v.mv_fwd = (int16_t*)(dev + mf); v.mv_bwd = (int16_t*)(dev + mk);
+        job->pics.push_back(m);
+        job->vpics.push_back(v);
+    }
+    for (size_t k = 0; k < scans.size(); k++) {
+        const Scan& x = scans[k];
+        PipePic& m = job->pics[k];
+        leon::VlcPic& v = job->vpics[k];
+        m.grp_off = take(gpad);
+        m.entries = take(pad256(ecap[k] * 4 + 4));
+        m.n_entries = (uint32_t)ecap[k];                 // the bound of the device lists (the kernels keep inside it)
+        v.grp_off = (uint32_t*)(dev + m.grp_off);
+        v.entries = (uint32_t*)(dev + m.entries);
+        v.entries_cap = (uint32_t)ecap[k];
+        for (size_t j = 0; j < x.code.size(); j++) {
+            leon::VlcSlice sl{};
+            sl.bytes = (const uint32_t*)dev;
+            sl.n_dwords = (uint32_t)(stream_pad / 4);
+            sl.n_bytes = (uint32_t)n;
+            sl.bit_pos = (uint32_t)x.pos[j];
+            sl.end_byte = (uint32_t)(j + 1 < x.code.size() ? (x.pos[j + 1] >> 3) - 4 : x.s.end_byte);
+            sl.code = x.code[j];
+            sl.pic = (uint32_t)k;
+            sl.scratch_cap = (uint32_t)scap[k][j];
+            sl.scratch = (uint32_t*)(dev + take(pad256(scap[k][j] * 4)));
+            job->slices.push_back(sl);
+        }
+    }
+    a->used = at;
+    if (!job->pics.empty()) job->gop_ts_ms = job->pics[0].ts_ms;
 }
 
 // one GOP shard: parse every picture of it straight into a pinned arena
@@ -144,6 +287,11 @@ void parse_gop(leon_pipeline* p, GopJob* job)
     const size_t mpad = pad256(mbs), vpad = pad256(mbs * 4), gpad = pad256(((size_t)p->vinfo.n_groups + 1) * 4);
     Arena* a = job->arena;
     a->used = 0;
+    if (p->gpu_parser) {
+        scan_gop_for_gpu(p, job, st, b, n, g);
+        leon_vlc_close(st);
+        return;
+    }
     leon_vlc_picture pic;
     for (;;) {
         const int rc = leon_vlc_next_picture_sync(st, &pic);      // parsed here, on this thread: no second thread per shard
@@ -155,7 +303,7 @@ void parse_gop(leon_pipeline* p, GopJob* job)
         }
         const size_t epad = pad256((size_t)pic.n_entries * 4 + 4);
         const size_t need = a->used + gpad + epad + 4 * mpad + 2 * vpad;
-        if (!arena_reserve(p, a, need)) {
+        if (!arena_reserve(p, a, need, need)) {
             job->status = LEON_ERR_NOMEM;
             job->err = "pinned staging allocation failed";
             break;
@@ -222,6 +370,66 @@ void parser_main(leon_pipeline* p)
     }
 }
 
+
+// gpu_parser: the slices of the whole window in one launch each of k_vlc_parse / k_vlc_offsets / k_vlc_gather
+// (leon_vlc_gpu.h), on the decoder's stream, in front of the reconstruction launches that read their output
+int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
+{
+    leon_decoder* d = p->dec;
+    size_t n_slices = 0, n_pics = 0;
+    for (GopJob* job : w->jobs) { n_slices += job->slices.size(); n_pics += job->vpics.size(); }
+    w->n_vpics = (uint32_t)n_pics;
+    if (!n_slices || !n_pics) return LEON_OK;
+    VlcRing& R = p->vlc_ring[(size_t)w->ring];
+    const size_t desc_bytes = pad256(n_slices * sizeof(leon::VlcSlice)) + pad256(n_pics * sizeof(leon::VlcPic));
+    const size_t dev_bytes = desc_bytes + pad256(n_slices * 4) + pad256(n_pics * 4);
+    if (dev_bytes > R.cap) {                     // the ring entry is ours: its previous window has been released
+        if (R.h) hipHostFree(R.h);
+        if (R.d) hipFree(R.d);
+        R.h = R.d = nullptr;
+        R.cap = dev_bytes + dev_bytes / 2;
+        if (hipHostMalloc((void**)&R.h, R.cap, hipHostMallocDefault) != hipSuccess || hipMalloc((void**)&R.d, R.cap) != hipSuccess) {
+            R.cap = 0;
+            return fail(LEON_ERR_NOMEM, "descriptor ring of the GPU parser");
+        }
+    }
+    if (n_pics > R.err_cap) {
+        if (R.h_err) hipHostFree(R.h_err);
+        R.err_cap = n_pics + n_pics / 2;
+        if (hipHostMalloc((void**)&R.h_err, R.err_cap * 4, hipHostMallocDefault) != hipSuccess) { R.err_cap = 0; R.h_err = nullptr; return fail(LEON_ERR_NOMEM, "error words of the GPU parser"); }
+    }
+    leon::VlcSlice* hs = (leon::VlcSlice*)R.h;
+    leon::VlcPic* hp = (leon::VlcPic*)(R.h + pad256(n_slices * sizeof(leon::VlcSlice)));
+    uint32_t* d_words = (uint32_t*)(R.d + desc_bytes);
+    uint32_t* d_err = (uint32_t*)(R.d + desc_bytes + pad256(n_slices * 4));
+    size_t si = 0, pi = 0;
+    for (GopJob* job : w->jobs) {
+        // what the kernels count in and report through starts at zero
+        if (job->zero_bytes) HIP_TRY(hipMemsetAsync(job->arena->dev + job->zero_begin, 0, job->zero_bytes, d->stream));
+        for (const leon::VlcSlice& sl : job->slices) {
+            hs[si] = sl;
+            hs[si].pic += (uint32_t)pi;
+            si++;
+        }
+        for (const leon::VlcPic& v : job->vpics) {
+            hp[pi] = v;
+            hp[pi].error = d_err + pi;             // one array per window: a single copy brings every picture's verdict back
+            pi++;
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(R.d, R.h, desc_bytes, hipMemcpyHostToDevice, d->stream));
+    HIP_TRY(hipMemsetAsync(d_err, 0, n_pics * 4, d->stream));
+    const leon::VlcSlice* ds = (const leon::VlcSlice*)R.d;
+    const leon::VlcPic* dp = (const leon::VlcPic*)(R.d + pad256(n_slices * sizeof(leon::VlcSlice)));
+    const int blocks = (int)((n_slices + 255) / 256);
+    hipLaunchKernelGGL(leon::k_vlc_parse, dim3(blocks), dim3(256), 0, d->stream, ds, d_words, (int)n_slices, dp, p->vgeom, p->d_vlc_tables);
+    hipLaunchKernelGGL(leon::k_vlc_offsets, dim3((unsigned)n_pics), dim3(256), 0, d->stream, dp, p->vgeom);
+    hipLaunchKernelGGL(leon::k_vlc_gather, dim3(blocks), dim3(256), 0, d->stream, ds, d_words, (int)n_slices, dp);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(R.h_err, d_err, n_pics * 4, hipMemcpyDeviceToHost, d->stream));
+    return LEON_OK;
+}
+
 // the pictures of one window as launches: per GOP the anchors rotate through three slots; a picture's
 // level is one more than the deepest picture it predicts from, and a level is one batch
 int submit_window(leon_pipeline* p, PipeWindow* w)
@@ -235,9 +443,10 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
     for (size_t j = 0; j < lanes; j++) {
         GopJob* job = w->jobs[j];
         // upload the GOP's arena; everything of this window is copied before its first launch
-        if (job->arena->used) {
-            HIP_TRY(hipMemcpyAsync(job->arena->dev, job->arena->host, job->arena->used, hipMemcpyHostToDevice, p->copy_stream));
-            p->st_upload += job->arena->used;
+        const size_t up = p->gpu_parser ? job->upload_bytes : job->arena->used;
+        if (up) {
+            HIP_TRY(hipMemcpyAsync(job->arena->dev, job->arena->host, up, hipMemcpyHostToDevice, p->copy_stream));
+            p->st_upload += up;
         }
         int older = -1, newer = -1, lv_older = -1, lv_newer = -1, n_anchor = 0;      // anchor slots (0..2 of the lane) and their levels
         for (const PipePic& m : job->pics) {
@@ -272,6 +481,10 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
     HIP_TRY(hipEventRecord(copied, p->copy_stream));
     HIP_TRY(hipStreamWaitEvent(d->stream, copied, 0));
     d->ev_pool.push_back(copied);
+    if (p->gpu_parser) {
+        const int rc = launch_gpu_parser(p, w);
+        if (rc != LEON_OK) return rc;
+    }
     std::vector<leon_sparse_picture> batch;
     for (auto& lvl : levels) {
         batch.clear();
@@ -417,6 +630,20 @@ void notify_main(leon_pipeline* p)
             w->status = LEON_ERR_HIP;
             pipe_fail(p, LEON_ERR_HIP, std::string("window ") + std::to_string(w->id) + ": " + hipGetErrorString(hipGetLastError()));
         }
+        if (w->status == LEON_OK && p->gpu_parser && w->n_vpics) {          // the GPU parser's verdict on every picture of the window
+            const uint32_t* e = p->vlc_ring[(size_t)w->ring].h_err;
+            for (uint32_t k = 0; k < w->n_vpics; k++)
+                if (e[k]) {
+                    static const char* const what[] = {"", "invalid macroblock address increment", "macroblock address outside the picture",
+                        "invalid macroblock type", "invalid motion code", "invalid coded block pattern", "invalid coefficient code",
+                        "coefficient index overflow", "bitstream ends inside a slice", "invalid DC size code", "slice larger than its scratch strip"};
+                    const uint32_t code = e[k] & 255u;
+                    w->status = LEON_ERR_INVALID;
+                    pipe_fail(p, LEON_ERR_INVALID, std::string("window ") + std::to_string(w->id) + ", picture " + std::to_string(k) + ", slice " +
+                              std::to_string(e[k] >> 8) + ": " + (code < sizeof(what) / sizeof(what[0]) ? what[code] : "malformed slice"));
+                    break;
+                }
+        }
         const int64_t id = w->id;
         const int st = w->status;
         bool quiet;
@@ -488,7 +715,10 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
                 return fail(LEON_ERR_INVALID, "key map entry %d does not point at a start code", g);
             }
             p->shard_begin.push_back(b);
-            p->shard_end.push_back(e);
+            // the shard takes the start code PREFIX of what follows along (00 00 01, not the code byte): its last slice
+            // then ends exactly as it does in the whole stream.  Cut at the key-map offset, a last macroblock coded in
+            // two bytes or less would look like the end of the data to the slice loop (jsv.js:1710-1760) and be dropped.
+            p->shard_end.push_back(std::min<uint64_t>(e + 3, bytes));
         }
     } else {            // no key map: the whole stream is one shard
         p->shard_begin.push_back(0);
@@ -537,6 +767,31 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
     if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(LEON_ERR_HIP, "copy stream");
     if (hipMalloc((void**)&p->d_rgba, (size_t)p->R * p->W * p->max_pics * p->frame_bytes) != hipSuccess) return bail(LEON_ERR_NOMEM, "RGBA ring");
     p->ring_owner.assign((size_t)p->R, -1);
+    p->gpu_parser = cfg->gpu_parser != 0;
+    if (p->gpu_parser) {
+        // the front end's tables in the order the kernels copy them to LDS (leon_vlc_gpu.h)
+        std::vector<leon_vlc_gpu_tables> src(1);
+        std::vector<leon::VlcTables> t(1);
+        leon_vlc_get_gpu_tables(src.data());
+        memcpy(t[0].fast12, src[0].fast12, sizeof(t[0].fast12));
+        memcpy(t[0].motion_s, src[0].motion_s, sizeof(t[0].motion_s));
+        memcpy(t[0].mba, src[0].mba, sizeof(t[0].mba));
+        memcpy(t[0].cbp, src[0].cbp, sizeof(t[0].cbp));
+        memcpy(t[0].mbtype, src[0].mbtype, sizeof(t[0].mbtype));
+        memcpy(t[0].dc_lum, src[0].dc_lum, sizeof(t[0].dc_lum));
+        memcpy(t[0].dc_chr, src[0].dc_chr, sizeof(t[0].dc_chr));
+        for (int i = 0; i < 64; i++) t[0].zz_off[i] = src[0].zz_off[i];
+        memcpy(t[0].coef16, src[0].coef16, sizeof(t[0].coef16));
+        if (hipMalloc((void**)&p->d_vlc_tables, sizeof(leon::VlcTables)) != hipSuccess) return bail(LEON_ERR_NOMEM, "GPU parser tables");
+        if (hipMemcpy(p->d_vlc_tables, t.data(), sizeof(leon::VlcTables), hipMemcpyHostToDevice) != hipSuccess) return bail(LEON_ERR_HIP, "GPU parser tables");
+        p->vgeom.mbw = p->vinfo.mb_width; p->vgeom.mbh = p->vinfo.mb_height;
+        p->vgeom.gy = p->vinfo.groups_y; p->vgeom.gc = p->vinfo.groups_c;
+        p->vgeom.n_y = 2 * p->vinfo.mb_height * p->vinfo.groups_y;
+        p->vgeom.n_c = p->vinfo.mb_height * p->vinfo.groups_c;
+        p->vgeom.n_groups = p->vinfo.n_groups;
+        p->vgeom.alpha = p->vinfo.has_alpha == 1;
+        p->vlc_ring.resize((size_t)p->R);
+    }
     const int n_arenas = p->W * (p->R + 1);
     for (int i = 0; i < n_arenas; i++) {
         Arena* a = new Arena();
@@ -637,6 +892,12 @@ void leon_pipeline_destroy(leon_pipeline* p)
         if (a->dev) hipFree(a->dev);
         delete a;
     }
+    for (VlcRing& r : p->vlc_ring) {
+        if (r.h) hipHostFree(r.h);
+        if (r.d) hipFree(r.d);
+        if (r.h_err) hipHostFree(r.h_err);
+    }
+    if (p->d_vlc_tables) hipFree(p->d_vlc_tables);
     if (p->d_rgba) hipFree(p->d_rgba);
     if (p->copy_stream) hipStreamDestroy(p->copy_stream);
     if (p->dec) leon_destroy(p->dec);

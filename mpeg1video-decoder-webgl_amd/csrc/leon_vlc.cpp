@@ -347,6 +347,11 @@ struct leon_vlc_stream {
     bool a_done = false, a_quit = false, a_eos = false;
     std::atomic<int> slice_error{0};
     char slice_err_text[160] = "";
+    // leon_vlc_scan_picture: headers and slice positions only
+    bool scan_only = false;
+    std::vector<int32_t> scan_code;
+    std::vector<uint64_t> scan_pos;
+    uint64_t scan_end = 0;
     std::mutex err_mu;
 };
 
@@ -774,6 +779,21 @@ int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
         code = r.next_start_code();
     }
     if (code >= 0) r.pos -= 32;                                    // rewind(32)
+    if (s->scan_only) {                                            // leon_vlc_scan_picture: the slices are not decoded here
+        s->scan_code.clear();
+        s->scan_pos.clear();
+        for (const SliceJob& j : s->jobs) { s->scan_code.push_back(j.code); s->scan_pos.push_back((uint64_t)j.bitpos); }
+        s->scan_end = (uint64_t)(r.pos >> 3);
+        out->type = type;
+        out->temporal_reference = s->temporal_reference;
+        out->ts_ms = s->ts_pending;
+        s->ts_pending = 0;
+        out->new_sequence = s->new_sequence ? 1 : 0;
+        s->new_sequence = false;
+        out->n_groups = s->info.n_groups;
+        out->n_slices = (uint32_t)s->jobs.size();
+        return 1;
+    }
 
     if (s->slice_out.size() < s->jobs.size()) s->slice_out.resize(s->jobs.size());
     for (size_t j = 0; j < s->jobs.size(); j++) s->slice_out[j].used = 0;
@@ -1090,6 +1110,49 @@ int leon_vlc_next_picture_sync(leon_vlc_stream* s, leon_vlc_picture* out)
     const int rc = next_picture_sync(s, out);
     s->info_out = s->info;
     return rc;
+}
+
+int leon_vlc_scan_picture(leon_vlc_stream* s, leon_vlc_picture_scan* out)
+{
+    if (!s || !out) return fail(LEON_VLC_ERR_INVALID, "null argument");
+    if (s->ended) return LEON_VLC_END;
+    g_err[0] = 0;
+    leon_vlc_picture p{};
+    s->scan_only = true;
+    const int rc = next_picture_sync(s, &p);
+    s->scan_only = false;
+    s->info_out = s->info;
+    if (rc != LEON_VLC_PICTURE) return rc;
+    memset(out, 0, sizeof(*out));
+    out->type = p.type;
+    out->temporal_reference = p.temporal_reference;
+    out->ts_ms = p.ts_ms;
+    out->new_sequence = p.new_sequence;
+    out->full_pel_fwd = s->full_pel_fwd; out->fwd_rsize = s->fwd_rsize;
+    out->full_pel_bwd = s->full_pel_bwd; out->bwd_rsize = s->bwd_rsize;
+    out->n_slices = p.n_slices;
+    out->slice_code = s->scan_code.data();
+    out->slice_bit_pos = s->scan_pos.data();
+    out->end_byte = s->scan_end;
+    return LEON_VLC_PICTURE;
+}
+
+int leon_vlc_get_gpu_tables(leon_vlc_gpu_tables* out)
+{
+    if (!out) return fail(LEON_VLC_ERR_INVALID, "null argument");
+    const Tables& T = tables();
+    memset(out, 0, sizeof(*out));
+    memcpy(out->fast12, T.fast12, sizeof(out->fast12));
+    memcpy(out->motion_s, T.motion_s, sizeof(out->motion_s));
+    for (size_t i = 0; i < 65536; i++) out->coef16[i] = T.coef.t[i];
+    for (size_t i = 0; i < 2048; i++) out->mba[i] = T.mba.t[i];
+    for (int t = 1; t <= 3; t++)
+        for (size_t i = 0; i < 64; i++) out->mbtype[t][i] = T.mbtype[t].t[i >> (6 - T.mbtype[t].max_len)];
+    for (size_t i = 0; i < 512; i++) out->cbp[i] = T.cbp.t[i];
+    for (size_t i = 0; i < 128; i++) out->dc_lum[i] = T.dc_lum.t[i];
+    for (size_t i = 0; i < 256; i++) out->dc_chr[i] = T.dc_chr.t[i];
+    for (int i = 0; i < 64; i++) out->zz_off[i] = (uint16_t)((kZigZag[i] >> 3) * 128 + (kZigZag[i] & 7) * 2);
+    return LEON_VLC_OK;
 }
 
 int leon_vlc_seek(leon_vlc_stream* s, double seconds, uint64_t* byte_offset)

@@ -74,7 +74,8 @@ class KernelStats(C.Structure):
 class PipelineConfig(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("parser_threads", C.c_int32), ("gops_per_window", C.c_int32),
                 ("windows_in_flight", C.c_int32), ("max_gop_pictures", C.c_int32), ("loop", C.c_int32),
-                ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("start_seconds", C.c_double)]
+                ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("start_seconds", C.c_double),
+                ("gpu_parser", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PipelineFrame(C.Structure):
@@ -365,7 +366,7 @@ class Pipeline:
     released right after.  read_frame(frame) works until the frame's window is released."""
 
     def __init__(self, data, device_id=0, parser_threads=0, gops_per_window=0, windows_in_flight=0, max_gop_pictures=0,
-                 loop=0, on_window=None, shard_index=0, shard_count=0, start_seconds=0.0):
+                 loop=0, on_window=None, shard_index=0, shard_count=0, start_seconds=0.0, gpu_parser=False):
         self.lib = load()
         self._data = (C.c_uint8 * len(data)).from_buffer_copy(data)      # must outlive the pipeline
         self._on_window = on_window
@@ -396,7 +397,7 @@ class Pipeline:
                 self.error = e
         self._cb = PIPELINE_CB(_cb)
         cfg = PipelineConfig(device_id, parser_threads, gops_per_window, windows_in_flight, max_gop_pictures, loop,
-                             shard_index, shard_count, float(start_seconds))
+                             shard_index, shard_count, float(start_seconds), 1 if gpu_parser else 0, 0)
         h = C.c_void_p()
         self.h = None
         rc = self.lib.leon_pipeline_create(C.byref(cfg), self._data, len(data), self._cb, None, C.byref(h))

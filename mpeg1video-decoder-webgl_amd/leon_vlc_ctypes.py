@@ -131,6 +131,12 @@ class Stream:
         self.lib.leon_vlc_get_keymap(self.h, offs, None, n)
         return [int(offs[i]) for i in range(n)]
 
+    def shard_ranges(self):
+        """(begin, end) of every GOP shard: from a key-map entry up to the next one's offset plus three -- the start
+        code prefix of what follows stays in, see leon_vlc_get_keymap in include/leon_vlc.h"""
+        offs, n = self.keymap(), len(self._bytes)
+        return [(b, min((offs[g + 1] if g + 1 < len(offs) else n) + 3, n)) for g, b in enumerate(offs)]
+
     def seek(self, seconds):
         off = C.c_uint64()
         if self.lib.leon_vlc_seek(self.h, float(seconds), C.byref(off)) != 0:

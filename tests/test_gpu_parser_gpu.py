@@ -1,0 +1,82 @@
+"""GPU: the slice layer decoded on the GPU (leon_pipeline_config.gpu_parser; csrc/leon_vlc_gpu.h: one lane per
+slice, decodeSlice .. decodeBlockGL of decoders/jsv.js:683-1525 as csrc/leon_vlc.cpp reads them) -- the pipeline's
+frames against the oracle run on the host front end's tensors, and against the pipeline with the host front end,
+on every fixture stream (I/P/B, several slices per row, custom matrices, yuva), on multi-GOP streams in several
+window / ring geometries, and on damaged streams."""
+import os
+
+import numpy as np
+import pytest
+
+from helpers import ROOT
+from test_pipeline_gpu import STREAMS, ibbp_stream, oracle_frames, run_pipeline
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def L():
+    import leon_ctypes
+    leon_ctypes.load()
+    return leon_ctypes
+
+
+@pytest.mark.parametrize("name", ["leon_synth_352x240", "slices5_ip_96x64", "custom_intra_ip_48x32", "tiny_ip_32x32", "yuva_ibbp_96x64"])
+def test_fixture_streams(L, name):
+    data = open(os.path.join(STREAMS, name + ".jsv"), "rb").read()
+    want = oracle_frames(data)
+    got, order, stats = run_pipeline(L, data, parser_threads=2, gops_per_window=2, gpu_parser=True)
+    assert set(got) == set(want) and stats["pictures"] == len(want)
+    for k in want:
+        bad = np.argwhere(got[k] != want[k])
+        assert bad.size == 0, "%s: frame %s differs in %d bytes, first at %s" % (name, k, len(bad), bad[0])
+    assert order == sorted(order)
+
+
+@pytest.mark.parametrize("window,threads,inflight", [(1, 1, 1), (3, 4, 2), (8, 2, 3)])
+def test_ibbp_windows_and_loops(L, window, threads, inflight):
+    data = ibbp_stream(208, 112, [6, 9, 3, 12, 6, 9, 12], seed=23 + window)
+    want = oracle_frames(data)
+    got, order, stats = run_pipeline(L, data, parser_threads=threads, gops_per_window=window, windows_in_flight=inflight, loop=2,
+                                     gpu_parser=True)
+    assert stats["pictures"] == 2 * len(want)
+    for (g, k), rgba in sorted(got.items()):
+        bad = np.argwhere((rgba != want[(g % 7, k)]).any(axis=2))
+        assert bad.size == 0, "GOP %d frame %d: %d pixels differ, rows %d..%d, columns %d..%d" % (
+            g, k, len(bad), bad[:, 0].min(), bad[:, 0].max(), bad[:, 1].min(), bad[:, 1].max())
+
+
+def test_same_frames_as_the_host_front_end_at_1080p(L):
+    """one 1080p GOP (68 slices per picture): byte for byte the frames of the pipeline that parses on the host"""
+    path = os.path.join(ROOT, "tools", "probe", "stream_1080p_2gop.bin")
+    if not os.path.exists(path):
+        pytest.skip("tools/probe/stream_1080p_2gop.bin is not there (tools/parse_bench.py writes it)")
+    data = open(path, "rb").read()
+    host, _, _ = run_pipeline(L, data, parser_threads=8, gops_per_window=2)
+    gpu, _, _ = run_pipeline(L, data, parser_threads=2, gops_per_window=2, gpu_parser=True)
+    assert set(host) == set(gpu) and len(gpu) == 24
+    for k in host:
+        assert np.array_equal(host[k], gpu[k]), k
+
+
+def test_damaged_streams_are_refused(L):
+    """bytes of one GOP overwritten: the run ends with an error instead of delivering garbage -- whichever layer
+    notices (the host's picture layer, or a slice on the GPU when its window completes)"""
+    import leon_vlc_ctypes as V
+    good = ibbp_stream(96, 64, [6, 6, 6], seed=9)
+    offs = V.Stream(good, threads=1).keymap()
+    for lo, hi, fill in ((60, 400, 0xFF), (200, 260, 0x00), (120, 121, 0x5A)):
+        bad = bytearray(good)
+        for i in range(offs[1] + lo, offs[1] + hi):
+            bad[i] = fill
+        pipe = L.Pipeline(bytes(bad), gops_per_window=1, parser_threads=1, max_gop_pictures=64, gpu_parser=True)
+        try:
+            try:
+                pipe.wait()
+                clean = True
+            except L.LeonError:
+                clean = False
+            # a single flipped byte may still be a valid stream; the long runs are not
+            assert not clean or hi - lo == 1
+        finally:
+            pipe.close()

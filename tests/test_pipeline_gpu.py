@@ -126,6 +126,16 @@ def test_ibbp_windows_and_loops(L, window, threads, inflight):
     assert ts == sorted(ts) and ts[1] - ts[0] == pytest.approx(40.0)      # 25 pictures/s
 
 
+def test_last_macroblock_of_a_gop_shard(L):
+    """seed 26: GOP 0 ends in a B picture whose last macroblock is two bytes of vectors; a shard cut at the key-map
+    offset itself loses it (see leon_vlc_get_keymap)"""
+    data = ibbp_stream(208, 112, [6, 9, 3, 12, 6, 9, 12], seed=26)
+    want = oracle_frames(data)
+    got, _, _ = run_pipeline(L, data, parser_threads=2, gops_per_window=3)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+
+
 def test_consumer_may_hold_windows(L):
     """frames stay valid until the window is released, from any thread; the pipeline waits for its ring"""
     data = ibbp_stream(96, 64, [6] * 6, seed=7)

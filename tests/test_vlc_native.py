@@ -228,8 +228,7 @@ def test_gop_shards_parse_like_the_whole_stream(name):
     offs = whole_st.keymap()
     assert len(offs) == whole_st.info.keymap_count >= 2
     got = []
-    for g, b in enumerate(offs):
-        e = offs[g + 1] if g + 1 < len(offs) else len(data)
+    for b, e in whole_st.shard_ranges():
         assert data[b:b + 4] == b"\x00\x00\x01\xc3"
         _, pics = all_pictures(data[b:e], threads=1)
         assert pics and pics[0]["type"] == 1
@@ -240,6 +239,37 @@ def test_gop_shards_parse_like_the_whole_stream(name):
         for k in ("coef_y", "coef_cb", "coef_cr", "repadd", "mv_fwd", "mv_bwd", "mb_dir"):
             if b.get(k) is not None:
                 assert np.array_equal(a[k], b[k]), (i, k)
+
+
+def test_a_shard_keeps_its_last_macroblock():
+    """a GOP whose last picture ends in a macroblock of two bytes (vectors, no coefficients): cut at the key-map
+    offset itself the slice loop would take those bytes for the end of the data (jsv.js:1710-1760) and drop the
+    macroblock; the shard therefore takes the 00 00 01 of what follows along"""
+    import jsv_writer as W
+    import synth as S
+    rng = np.random.default_rng(26)
+    pics, starts = [], []
+    for n in (6, 9, 3):
+        starts.append(len(pics))
+        for ptype, disp, f, b in S.gop_ibbp(n):
+            t = S.make_picture(rng, 208, 112, ptype, force_dir=2 if (ptype == S.PIC_B and f is None) else None)
+            t["display"] = disp
+            pics.append(t)
+    data = W.write_stream(pics, 208, 112, 208, 112, gop_starts=starts)[0]
+    whole_st, whole = all_pictures(data, threads=1)
+    assert whole[5]["type"] == 3 and whole[5]["mb_dir"][-1] != 0          # the picture and the macroblock this is about
+    got = []
+    for b, e in whole_st.shard_ranges():
+        got += all_pictures(data[b:e], threads=1)[1]
+    assert len(got) == len(whole)
+    for i, (a, b) in enumerate(zip(got, whole)):
+        for k in ("coef_y", "coef_cb", "coef_cr", "repadd", "mv_fwd", "mv_bwd", "mb_dir"):
+            if b.get(k) is not None:
+                assert np.array_equal(a[k], b[k]), (i, k)
+    # ... and cut at the offset itself it is lost
+    offs = whole_st.keymap()
+    short = all_pictures(data[offs[0]:offs[1]], threads=1)[1]
+    assert short[5]["mb_dir"][-1] == 0
 
 
 def test_corruption_fuzz_under_address_and_ub_sanitizers(tmp_path):

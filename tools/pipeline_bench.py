@@ -28,6 +28,7 @@ def main():
     ap.add_argument("--threads", type=int, default=16)
     ap.add_argument("--window", type=int, default=32)
     ap.add_argument("--inflight", type=int, default=2)
+    ap.add_argument("--gpu-parser", action="store_true", help="decode the slice layer on the GPU (leon_pipeline_config.gpu_parser)")
     a = ap.parse_args()
     cached = os.path.join(ROOT, "tools", "probe", "stream_1080p_%dgop.bin" % a.gops)
     if os.path.exists(cached):
@@ -37,7 +38,7 @@ def main():
         data = parse_bench.make_stream(a.gops, "/tmp/leon_parse_bench_%d.jsv" % a.gops)
     import leon_ctypes as L
     t0 = time.perf_counter()
-    pipe = L.Pipeline(data, parser_threads=a.threads, gops_per_window=a.window, windows_in_flight=a.inflight, loop=a.loop)
+    pipe = L.Pipeline(data, parser_threads=a.threads, gops_per_window=a.window, windows_in_flight=a.inflight, loop=a.loop, gpu_parser=a.gpu_parser)
     pipe.wait()
     wall = time.perf_counter() - t0
     s = pipe.stats()
@@ -48,6 +49,7 @@ def main():
                   % (pipe.info.frame_width, pipe.info.frame_height),
         "value": s["pictures"] / s["seconds"], "macroblocks_per_s": s["pictures"] * mbs / s["seconds"],
         "pictures": s["pictures"], "seconds": s["seconds"], "wall_seconds_incl_setup": wall, "windows": s["windows"],
+        "slice_layer": "GPU (csrc/leon_vlc_gpu.h)" if a.gpu_parser else "host threads (libleon_vlc.so)",
         "parser_threads": pipe.info.parser_threads, "gops_per_window": pipe.info.gops_per_window,
         "parse_seconds_summed_over_threads": s["parse_seconds_sum"],
         "parser_pictures_per_s_per_thread": s["pictures"] / s["parse_seconds_sum"] if s["parse_seconds_sum"] else None,
