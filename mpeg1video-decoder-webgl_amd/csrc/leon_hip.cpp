@@ -143,7 +143,7 @@ struct leon_decoder {
     int next_stage = 0;
     PicDesc* d_desc_ring = nullptr;   // kDescRing descriptors for ad-hoc submits
     PicDesc* h_desc_pinned = nullptr;
-    static constexpr int kDescRing = 4096;
+    static constexpr int kDescRing = 65536;    // a wrap waits for the stream: rare enough with windows of a few thousand pictures
     int desc_head = 0;
     hipEvent_t desc_wrap_ev = nullptr;
     // rgba

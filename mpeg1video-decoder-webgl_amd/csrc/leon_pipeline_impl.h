@@ -86,6 +86,7 @@ struct leon_pipeline {
     hipStream_t copy_stream = nullptr;
     uint8_t* d_rgba = nullptr;                        // R ring entries of W * max_pics frames
     bool gpu_parser = false;
+    hipStream_t vlc_stream = nullptr;                 // the parser kernels of window n + 1 run beside the reconstruction of window n
     leon::VlcTables* d_vlc_tables = nullptr;
     leon::VlcGeom vgeom{};
     std::vector<VlcRing> vlc_ring;
@@ -188,7 +189,7 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
     const size_t max_entries = (size_t)p->vinfo.coded_width * p->vinfo.coded_height * (p->vinfo.has_alpha == 1 ? 5 : 3) / 2;
     const size_t stream_pad = pad256(n + 16);
     // sizes first: the arena may move when it grows
-    const size_t zero_per_pic = 256 + gpad + 4 * mpad + 2 * vpad;
+    const size_t zero_per_pic = gpad + 4 * mpad + 2 * vpad;
     size_t need = stream_pad + scans.size() * zero_per_pic;
     std::vector<size_t> ecap(scans.size());
     std::vector<std::vector<size_t>> scap(scans.size());
@@ -199,12 +200,12 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
         for (size_t j = 0; j < x.code.size(); j++) {
             const uint64_t begin = x.pos[j] >> 3, end = j + 1 < x.code.size() ? (x.pos[j + 1] >> 3) - 4 : x.s.end_byte;
             const size_t nb = end > begin ? (size_t)(end - begin) : 0;
-            scap[k][j] = 4 * nb + 72;                    // an entry takes at least two bits, a block record one word more
+            scap[k][j] = nb;                             // bytes of the slice: its strip is sized from them below
             pic_words += 4 * nb;
         }
         ecap[k] = std::min(std::max(pic_words, (size_t)64), max_entries);
         need += gpad + pad256(ecap[k] * 4 + 4);
-        for (size_t c : scap[k]) need += pad256(c * 4);
+        for (size_t c : scap[k]) need += pad256((2 * c + 8 + 4 * c + 64) * 4);
     }
     if (!arena_reserve(p, a_of(job), stream_pad, need)) { job->status = LEON_ERR_NOMEM; job->err = "staging allocation failed"; return; }
     Arena* a = job->arena;
@@ -226,17 +227,13 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
         v.type = x.s.type;
         v.full_pel_fwd = x.s.full_pel_fwd; v.fwd_rsize = x.s.fwd_rsize;
         v.full_pel_bwd = x.s.full_pel_bwd; v.bwd_rsize = x.s.bwd_rsize;
-        v.error = (uint32_t*)(dev + take(256));
-        v.grp_cnt = (uint32_t*)(dev + take(gpad));
+        v.zbase = dev + take(gpad);                      // [counters | qscale | intra | repadd | mb_dir | mv_fwd | mv_bwd]: VlcGeom's offsets
         m.qscale = take(mpad); m.intra = take(mpad);
         const size_t ra = take(mpad), md = take(mpad), mf = take(vpad), mk = take(vpad);
         m.repadd = x.s.type != LEON_PIC_I ? ra : kNone;
         m.mb_dir = x.s.type == LEON_PIC_B ? md : kNone;
         m.mv_fwd = x.s.type != LEON_PIC_I ? mf : kNone;
         m.mv_bwd = x.s.type == LEON_PIC_B ? mk : kNone;
-        v.qscale = (uint8_t*)(dev + m.qscale); v.intra = (uint8_t*)(dev + m.intra);
-        v.repadd = (uint8_t*)(dev + ra); v.mb_dir = (uint8_t*)(dev + md);
-        v.mv_fwd = (int16_t*)(dev + mf); v.mv_bwd = (int16_t*)(dev + mk);
         job->pics.push_back(m);
         job->vpics.push_back(v);
     }
@@ -259,8 +256,10 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
             sl.end_byte = (uint32_t)(j + 1 < x.code.size() ? (x.pos[j + 1] >> 3) - 4 : x.s.end_byte);
             sl.code = x.code[j];
             sl.pic = (uint32_t)k;
-            sl.scratch_cap = (uint32_t)scap[k][j];
-            sl.scratch = (uint32_t*)(dev + take(pad256(scap[k][j] * 4)));
+            // a coded block takes at least four bits (one header), an entry at least two
+            sl.hdr_cap = (uint32_t)(2 * scap[k][j] + 8);
+            sl.ent_cap = (uint32_t)(4 * scap[k][j] + 64);
+            sl.scratch = (uint32_t*)(dev + take(pad256(((size_t)sl.hdr_cap + sl.ent_cap) * 4)));
             job->slices.push_back(sl);
         }
     }
@@ -375,7 +374,6 @@ void parser_main(leon_pipeline* p)
 // (leon_vlc_gpu.h), on the decoder's stream, in front of the reconstruction launches that read their output
 int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
 {
-    leon_decoder* d = p->dec;
     size_t n_slices = 0, n_pics = 0;
     for (GopJob* job : w->jobs) { n_slices += job->slices.size(); n_pics += job->vpics.size(); }
     w->n_vpics = (uint32_t)n_pics;
@@ -405,28 +403,24 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
     size_t si = 0, pi = 0;
     for (GopJob* job : w->jobs) {
         // what the kernels count in and report through starts at zero
-        if (job->zero_bytes) HIP_TRY(hipMemsetAsync(job->arena->dev + job->zero_begin, 0, job->zero_bytes, d->stream));
+        if (job->zero_bytes) HIP_TRY(hipMemsetAsync(job->arena->dev + job->zero_begin, 0, job->zero_bytes, p->vlc_stream));
         for (const leon::VlcSlice& sl : job->slices) {
             hs[si] = sl;
             hs[si].pic += (uint32_t)pi;
             si++;
         }
-        for (const leon::VlcPic& v : job->vpics) {
-            hp[pi] = v;
-            hp[pi].error = d_err + pi;             // one array per window: a single copy brings every picture's verdict back
-            pi++;
-        }
+        for (const leon::VlcPic& v : job->vpics) hp[pi++] = v;
     }
-    HIP_TRY(hipMemcpyAsync(R.d, R.h, desc_bytes, hipMemcpyHostToDevice, d->stream));
-    HIP_TRY(hipMemsetAsync(d_err, 0, n_pics * 4, d->stream));
+    HIP_TRY(hipMemcpyAsync(R.d, R.h, desc_bytes, hipMemcpyHostToDevice, p->vlc_stream));
+    HIP_TRY(hipMemsetAsync(d_err, 0, n_pics * 4, p->vlc_stream));
     const leon::VlcSlice* ds = (const leon::VlcSlice*)R.d;
     const leon::VlcPic* dp = (const leon::VlcPic*)(R.d + pad256(n_slices * sizeof(leon::VlcSlice)));
     const int blocks = (int)((n_slices + 255) / 256);
-    hipLaunchKernelGGL(leon::k_vlc_parse, dim3(blocks), dim3(256), 0, d->stream, ds, d_words, (int)n_slices, dp, p->vgeom, p->d_vlc_tables);
-    hipLaunchKernelGGL(leon::k_vlc_offsets, dim3((unsigned)n_pics), dim3(256), 0, d->stream, dp, p->vgeom);
-    hipLaunchKernelGGL(leon::k_vlc_gather, dim3(blocks), dim3(256), 0, d->stream, ds, d_words, (int)n_slices, dp);
+    hipLaunchKernelGGL(leon::k_vlc_parse, dim3(blocks), dim3(256), 0, p->vlc_stream, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
+    hipLaunchKernelGGL(leon::k_vlc_offsets, dim3((unsigned)n_pics), dim3(256), 0, p->vlc_stream, dp, p->vgeom);
+    hipLaunchKernelGGL(leon::k_vlc_gather, dim3((unsigned)((n_slices + 3) / 4)), dim3(256), 0, p->vlc_stream, ds, d_words, (int)n_slices, dp, p->vgeom);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(R.h_err, d_err, n_pics * 4, hipMemcpyDeviceToHost, d->stream));
+    HIP_TRY(hipMemcpyAsync(R.h_err, d_err, n_pics * 4, hipMemcpyDeviceToHost, p->vlc_stream));
     return LEON_OK;
 }
 
@@ -479,11 +473,20 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
     hipEvent_t copied = get_event(d);
     if (!copied) return LEON_ERR_HIP;
     HIP_TRY(hipEventRecord(copied, p->copy_stream));
-    HIP_TRY(hipStreamWaitEvent(d->stream, copied, 0));
-    d->ev_pool.push_back(copied);
     if (p->gpu_parser) {
+        // upload -> parser kernels (their own stream) -> reconstruction (the decoder's stream)
+        HIP_TRY(hipStreamWaitEvent(p->vlc_stream, copied, 0));
+        d->ev_pool.push_back(copied);
         const int rc = launch_gpu_parser(p, w);
         if (rc != LEON_OK) return rc;
+        hipEvent_t parsed = get_event(d);
+        if (!parsed) return LEON_ERR_HIP;
+        HIP_TRY(hipEventRecord(parsed, p->vlc_stream));
+        HIP_TRY(hipStreamWaitEvent(d->stream, parsed, 0));
+        d->ev_pool.push_back(parsed);
+    } else {
+        HIP_TRY(hipStreamWaitEvent(d->stream, copied, 0));
+        d->ev_pool.push_back(copied);
     }
     std::vector<leon_sparse_picture> batch;
     for (auto& lvl : levels) {
@@ -773,15 +776,23 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
         std::vector<leon_vlc_gpu_tables> src(1);
         std::vector<leon::VlcTables> t(1);
         leon_vlc_get_gpu_tables(src.data());
-        memcpy(t[0].fast12, src[0].fast12, sizeof(t[0].fast12));
-        memcpy(t[0].motion_s, src[0].motion_s, sizeof(t[0].motion_s));
-        memcpy(t[0].mba, src[0].mba, sizeof(t[0].mba));
-        memcpy(t[0].cbp, src[0].cbp, sizeof(t[0].cbp));
-        memcpy(t[0].mbtype, src[0].mbtype, sizeof(t[0].mbtype));
-        memcpy(t[0].dc_lum, src[0].dc_lum, sizeof(t[0].dc_lum));
-        memcpy(t[0].dc_chr, src[0].dc_chr, sizeof(t[0].dc_chr));
+        // 16 bits per entry for the part that lives in LDS: fast12 as {length:4, end of block:1, run:5, level:6},
+        // the others as (length << 8) | value
+        for (int i = 0; i < 4096; i++) {
+            const uint32_t f = src[0].fast12[i];
+            const int len = (int)(f & 0x7f), run = (int)((f >> 8) & 0xff), level = (int)(int16_t)(f >> 16);
+            if (len > 15 || run > 31 || level < -32 || level > 31) { leon_pipeline_destroy(p); return fail(LEON_ERR_INVALID, "coefficient table does not fit 16 bits"); }
+            t[0].fast12[i] = (uint16_t)(len | ((f & 0x80u) ? 0x10 : 0) | (run << 5) | ((level & 63) << 10));
+        }
+        auto pack = [](int32_t e) { return (uint16_t)(((e >> 16) << 8) | (e & 0xff)); };
+        for (int i = 0; i < 2048; i++) { t[0].motion_s[i] = pack(src[0].motion_s[i]); t[0].mba[i] = pack(src[0].mba[i]); }
+        for (int i = 0; i < 512; i++) t[0].cbp[i] = pack(src[0].cbp[i]);
+        for (int k = 0; k < 4; k++) for (int i = 0; i < 64; i++) t[0].mbtype[k][i] = pack(src[0].mbtype[k][i]);
+        for (int i = 0; i < 128; i++) t[0].dc_lum[i] = pack(src[0].dc_lum[i]);
+        for (int i = 0; i < 256; i++) t[0].dc_chr[i] = pack(src[0].dc_chr[i]);
         for (int i = 0; i < 64; i++) t[0].zz_off[i] = src[0].zz_off[i];
         memcpy(t[0].coef16, src[0].coef16, sizeof(t[0].coef16));
+        if (hipStreamCreateWithFlags(&p->vlc_stream, hipStreamNonBlocking) != hipSuccess) return bail(LEON_ERR_HIP, "parser stream");
         if (hipMalloc((void**)&p->d_vlc_tables, sizeof(leon::VlcTables)) != hipSuccess) return bail(LEON_ERR_NOMEM, "GPU parser tables");
         if (hipMemcpy(p->d_vlc_tables, t.data(), sizeof(leon::VlcTables), hipMemcpyHostToDevice) != hipSuccess) return bail(LEON_ERR_HIP, "GPU parser tables");
         p->vgeom.mbw = p->vinfo.mb_width; p->vgeom.mbh = p->vinfo.mb_height;
@@ -790,6 +801,17 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
         p->vgeom.n_c = p->vinfo.mb_height * p->vinfo.groups_c;
         p->vgeom.n_groups = p->vinfo.n_groups;
         p->vgeom.alpha = p->vinfo.has_alpha == 1;
+        {   // a picture's counters and maps, in the order scan_gop_for_gpu lays them out
+            const size_t mbs = (size_t)p->vinfo.mb_width * p->vinfo.mb_height;
+            const size_t mpad = pad256(mbs), vpad = pad256(mbs * 4), gpad = pad256(((size_t)p->vinfo.n_groups + 1) * 4);
+            p->vgeom.off_cnt = 0;
+            p->vgeom.off_qscale = (uint32_t)gpad;
+            p->vgeom.off_intra = (uint32_t)(gpad + mpad);
+            p->vgeom.off_repadd = (uint32_t)(gpad + 2 * mpad);
+            p->vgeom.off_mb_dir = (uint32_t)(gpad + 3 * mpad);
+            p->vgeom.off_mv_fwd = (uint32_t)(gpad + 4 * mpad);
+            p->vgeom.off_mv_bwd = (uint32_t)(gpad + 4 * mpad + vpad);
+        }
         p->vlc_ring.resize((size_t)p->R);
     }
     const int n_arenas = p->W * (p->R + 1);
@@ -898,6 +920,7 @@ void leon_pipeline_destroy(leon_pipeline* p)
         if (r.h_err) hipHostFree(r.h_err);
     }
     if (p->d_vlc_tables) hipFree(p->d_vlc_tables);
+    if (p->vlc_stream) hipStreamDestroy(p->vlc_stream);
     if (p->d_rgba) hipFree(p->d_rgba);
     if (p->copy_stream) hipStreamDestroy(p->copy_stream);
     if (p->dec) leon_destroy(p->dec);

@@ -12,49 +12,54 @@
 // 128 GOPs x 12 pictures: ~100 000 independent slices, one LANE each.  16 host cores parse 14 k pictures/s;
 // the reconstruction kernels take 220 k/s.
 //
-//   k_vlc_parse    one lane per slice: macroblock maps straight into the picture's arrays; coefficients as
-//                  block records (header {group id, count} + entries) into the slice's scratch strip, the
-//                  count added to the group's counter.
+//   k_vlc_parse    one lane per slice: macroblock maps straight into the picture's arrays; coefficients into the
+//                  slice's scratch strip -- one header word {group id, count} per coded block at its front, the
+//                  entries behind, both in decoding order -- and the count added to the group's counter.
 //   k_vlc_offsets  one workgroup per picture: exclusive scan of the group counters -> grp_off (what
 //                  leon_sparse_picture wants), counters back to zero (they become cursors).
-//   k_vlc_gather   one lane per slice again: every block record moves to grp_off[group] + cursor (atomic add
-//                  of the block's count).  Entries of a group are "in no particular order" (include/leon_vlc.h).
+//   k_vlc_gather   one WAVE per slice: 64 block headers at a time, a wave prefix sum of their counts finds each
+//                  block's entries, which move to grp_off[group] + cursor (atomic add of the block's count).
+//                  Entries of a group are "in no particular order" (include/leon_vlc.h).
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
 namespace leon {
 
-struct VlcTables {               // device copy of leon_vlc_gpu_tables, LDS part first
-    uint32_t fast12[4096];
-    int32_t motion_s[2048];
-    int32_t mba[2048];
-    int32_t cbp[512];
-    int32_t mbtype[4][64];
-    int32_t dc_lum[128], dc_chr[256];
-    uint32_t zz_off[64];
+// Device copy of the front end's tables (leon_vlc_get_gpu_tables), the LDS part first and in 16 bits:
+//   fast12: bits 0..3 length (0 = longer code or escape), bit 4 end of block, bits 5..9 run, bits 10..15 level
+//   the others: (length << 8) | value, 0 = invalid code
+struct VlcTables {
+    uint16_t fast12[4096];
+    uint16_t motion_s[2048];
+    uint16_t mba[2048];
+    uint16_t cbp[512];
+    uint16_t mbtype[4][64];
+    uint16_t dc_lum[128], dc_chr[256];
+    uint16_t zz_off[64];
     int32_t coef16[65536];       // stays in global memory: long codes and escapes only
 };
-static constexpr int kVlcLdsWords = 4096 + 2048 + 2048 + 512 + 256 + 128 + 256 + 64;
+static constexpr int kVlcLdsWords = (4096 + 2048 + 2048 + 512 + 256 + 128 + 256 + 64) / 2;
+// every lane reads its slice through a ring of 16 dwords in LDS: dword i of lane L at ring[(i & 15) * 64 + L]
+#ifndef LEON_VLC_RING
+#define LEON_VLC_RING 1
+#endif
+static constexpr int kVlcRingDwords = 16;
+static constexpr int kVlcRingBytesPerWave = kVlcRingDwords * 64 * 4;
 
 struct VlcGeom {
     int32_t mbw, mbh, gy, gc, n_y, n_c, n_groups, alpha;
+    // byte offsets of a picture's arrays from VlcPic::zbase (the same for every picture: wave-uniform)
+    uint32_t off_cnt, off_qscale, off_intra, off_repadd, off_mb_dir, off_mv_fwd, off_mv_bwd, pad;
 };
 
 struct VlcPic {                  // one picture of the window
     int32_t type, full_pel_fwd, fwd_rsize, full_pel_bwd, bwd_rsize, pad;
-    uint8_t* qscale;
-    uint8_t* intra;
-    uint8_t* repadd;
-    uint8_t* mb_dir;
-    int16_t* mv_fwd;
-    int16_t* mv_bwd;
-    uint32_t* grp_cnt;           // [n_groups + 1], zero on entry
+    char* zbase;                 // zero on entry: group counters [n_groups + 1] and the macroblock maps, at VlcGeom's offsets
     uint32_t* grp_off;           // [n_groups + 1]
     uint32_t* entries;
     uint32_t entries_cap;
     uint32_t pad2;
-    uint32_t* error;             // one word, zero on entry; first error code of any of its slices
 };
 
 struct VlcSlice {
@@ -65,40 +70,84 @@ struct VlcSlice {
     uint32_t end_byte;           // first byte behind the slice
     int32_t code;                // slice_vertical_position
     uint32_t pic;
-    uint32_t scratch_cap;        // words
-    uint32_t pad;
-    uint32_t* scratch;
+    uint32_t hdr_cap;            // block headers the strip has room for ...
+    uint32_t ent_cap;            // ... and entries behind them
+    uint32_t* scratch;           // [hdr_cap headers][ent_cap entries]
 };
 
 enum { VLC_ERR_MBA = 1, VLC_ERR_ADDR, VLC_ERR_TYPE, VLC_ERR_MOTION, VLC_ERR_CBP, VLC_ERR_COEF, VLC_ERR_INDEX, VLC_ERR_END, VLC_ERR_DC,
        VLC_ERR_SCRATCH };
 
+// The lane's view of its slice.  The stream does not come from memory symbol by symbol -- with 64 lanes in a wave some
+// lane would be waiting for a load at every step, and the wave with it -- but through the ring: the lanes top their
+// rings up TOGETHER (sync, below) with loads that go straight to LDS, half a ring ahead of what is being read, so
+// that the wait in front of the next top-up finds them long landed.  Reading a dword is an LDS access.
 struct VlcWin {
     const uint32_t* base;
-    uint32_t next, nd;           // next dword to load, dwords there are
+    uint32_t next, nd;           // next dword to take from the ring, dwords the stream copy has
+    uint32_t safe, loaded;       // [next, safe) is in the ring, [safe, loaded) is on its way
     uint64_t w;                  // the stream from `pos` on, left aligned, `avail` bits valid, zeros below
     int avail;
     uint32_t pos;                // in bits, from base
-    __device__ __forceinline__ void init(const uint32_t* b, uint32_t n_dwords, uint32_t bit_pos)
+    uint32_t* ring;              // this wave's ring (LDS), already offset by the lane
+    __device__ __forceinline__ void request(uint32_t* wave_ring, int lane, uint32_t upto)      // dwords [loaded, upto), upto - next <= 16
+    {
+#pragma unroll
+        for (int i = 0; i < kVlcRingDwords; i++) {
+            const uint32_t idx = loaded + (((uint32_t)i - loaded) & 15u);      // the dword >= loaded that lives in slot i
+            if (idx < upto) {
+                if (idx < nd) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + idx),
+                                                                (__attribute__((address_space(3))) void*)(wave_ring + i * 64), 4, 0, 0);
+                else wave_ring[i * 64 + lane] = 0u;
+            }
+        }
+        loaded = upto;
+    }
+    __device__ __forceinline__ void init(const uint32_t* b, uint32_t n_dwords, uint32_t bit_pos, uint32_t* wave_ring, int lane)
     {
         base = b; nd = n_dwords; pos = bit_pos;
-        next = bit_pos >> 5;
+        next = loaded = bit_pos >> 5;
+        ring = wave_ring + lane;
+#if LEON_VLC_RING
+        request(wave_ring, lane, next + kVlcRingDwords);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#endif
+        safe = loaded;
         const uint32_t lead = bit_pos & 31u;
-        const uint32_t d0 = load(), d1 = load();
+        const uint32_t d0 = take(), d1 = take();
         w = (((uint64_t)d0 << 32) | d1) << lead;
         avail = 64 - (int)lead;
     }
-    __device__ __forceinline__ uint32_t load()
+    __device__ __forceinline__ uint32_t take()
     {
+#if LEON_VLC_RING
+        const uint32_t d = __builtin_bswap32(ring[(next & 15u) * 64u]);
+#else
         const uint32_t d = next < nd ? __builtin_bswap32(__builtin_nontemporal_load(base + next)) : 0u;
+#endif
         next++;
         return d;
+    }
+    // Top-up point (wave-uniform): called in front of every syntax element; between two calls a lane takes at most one
+    // dword.  When any lane is down to half a ring, or to its last landed dwords: wait for what is on its way
+    // (requested half a ring ago), then request up to a full ring again.
+    __device__ __forceinline__ void sync(uint32_t* wave_ring, int lane)
+    {
+#if !LEON_VLC_RING
+        return;
+#endif
+        const bool low = loaded - next < 8u || safe - next < 2u;
+        if (__builtin_amdgcn_ballot_w64(low) != 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            safe = loaded;
+            request(wave_ring, lane, next + kVlcRingDwords);
+        }
     }
     // at least 32 valid bits afterwards (one symbol of the syntax takes at most 28)
     __device__ __forceinline__ void fill()
     {
         if (avail <= 32) {
-            w |= (uint64_t)load() << (32 - avail);
+            w |= (uint64_t)take() << (32 - avail);
             avail += 32;
         }
     }
@@ -115,13 +164,13 @@ struct VlcWin {
 };
 
 struct VlcLds {
-    uint32_t fast12[4096];
-    int32_t motion_s[2048];
-    int32_t mba[2048];
-    int32_t cbp[512];
-    int32_t mbtype[4][64];
-    int32_t dc_lum[128], dc_chr[256];
-    uint32_t zz_off[64];
+    uint16_t fast12[4096];
+    uint16_t motion_s[2048];
+    uint16_t mba[2048];
+    uint16_t cbp[512];
+    uint16_t mbtype[4][64];
+    uint16_t dc_lum[128], dc_chr[256];
+    uint16_t zz_off[64];
 };
 static_assert(sizeof(VlcLds) == kVlcLdsWords * 4, "LDS copy and VlcTables disagree");
 
@@ -130,18 +179,25 @@ struct VlcCtx {                  // per lane: the state a slice carries from mac
     int fw_h, fw_v, fw_h_prev, fw_v_prev, bw_h, bw_v, bw_h_prev, bw_v_prev, prev_dir;
     int dc_y, dc_cr, dc_cb, dc_a, qs;
     int mb_intra;
-    uint32_t* out;               // next free word of the scratch strip
-    uint32_t* out_end;
+    uint32_t* hdr;               // next free block header of the scratch strip
+    uint32_t* ent;               // next free entry
+    uint32_t* hdr_end;
+    uint32_t* ent_end;
+    char* zbase;                 // the picture's counters and maps
+    int type, full_pel_fwd, fwd_rsize, full_pel_bwd, bwd_rsize;
+    uint32_t* wave_ring;         // LDS ring of the wave (VlcWin::sync)
+    int lane;
 };
+#define VLC_SYNC(r, c) (r).sync((c).wave_ring, (c).lane)
 
 // decoders/jsv.js:831-893, as motion_component of leon_vlc.cpp
 __device__ __forceinline__ int vlc_motion_component(VlcWin& r, const VlcLds& L, int prev, int rsize, int f, int& err)
 {
     r.fill();
-    const int32_t e = L.motion_s[r.peek(11)];
+    const uint32_t e = L.motion_s[r.peek(11)];
     if (e == 0) { err = VLC_ERR_MOTION; return prev; }
-    r.drop(e >> 16);
-    const int code = (e & 0xffff) - 16;
+    r.drop((int)(e >> 8));
+    const int code = (int)(e & 0xffu) - 16;
     int d = code;
     if (code != 0 && f != 1) {
         const int res = (int)r.get(rsize);
@@ -155,55 +211,61 @@ __device__ __forceinline__ int vlc_motion_component(VlcWin& r, const VlcLds& L, 
 }
 
 // decoders/jsv.js:1338-1525 (decodeBlockGL), as decode_block of leon_vlc.cpp; returns an error code or 0
-__device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTables* __restrict__ T, const VlcGeom& G, const VlcPic& P,
-                                         VlcCtx& c, int block)
+// COMP (which DC predictor, which DC table): 0 luma blocks 0..3, 1 block 4, 2 block 5, 3 the A blocks 6..9 -- a template
+// parameter: chosen at run time, the predictor would be read through a computed address and the whole context
+// would live in scratch memory
+template <int COMP>
+__device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTables* __restrict__ T, const VlcGeom& G, VlcCtx& c, int block)
 {
     uint32_t gid, bq;
-    if (block < 4 || block >= 6) {                           // luma, or the A component (blocks 6..9, placed like luma)
-        const int lb = block < 4 ? block : block - 6;
+    if (COMP == 0 || COMP == 3) {                            // luma, or the A component (blocks 6..9, placed like luma)
+        const int lb = COMP == 0 ? block : block - 6;
         const int qb = c.mb_col * 2 + (lb & 1);
-        gid = (uint32_t)((2 * c.mb_row + (lb >> 1)) * G.gy + (qb >> 3)) + (block < 4 ? 0u : (uint32_t)(G.n_y + 2 * G.n_c));
+        gid = (uint32_t)((2 * c.mb_row + (lb >> 1)) * G.gy + (qb >> 3)) + (COMP == 0 ? 0u : (uint32_t)(G.n_y + 2 * G.n_c));
         bq = (uint32_t)(qb & 7);
     } else {
-        gid = (uint32_t)(G.n_y + (block == 5 ? G.n_c : 0) + c.mb_row * G.gc + (c.mb_col >> 3));
+        gid = (uint32_t)(G.n_y + (COMP == 2 ? G.n_c : 0) + c.mb_row * G.gc + (c.mb_col >> 3));
         bq = (uint32_t)(c.mb_col & 7);
     }
     const uint32_t boff = (bq * 16u) << 16;
-    if (c.out + 65 > c.out_end) return VLC_ERR_SCRATCH;      // a block record: header + at most 64 entries
-    uint32_t* const rec = c.out;
+    if (c.hdr >= c.hdr_end || c.ent + 64 > c.ent_end) return VLC_ERR_SCRATCH;      // a block: one header, at most 64 entries
+    uint32_t* const rec = c.ent;
     int k = 0, n = 0;
     if (c.mb_intra) {
+        VLC_SYNC(r, c);
         r.fill();
-        const int32_t e = block < 4 || block >= 6 ? L.dc_lum[r.peek(7)] : L.dc_chr[r.peek(8)];
+        const uint32_t e = COMP == 0 || COMP == 3 ? L.dc_lum[r.peek(7)] : L.dc_chr[r.peek(8)];
         if (e == 0) return VLC_ERR_DC;
-        r.drop(e >> 16);
-        const int size = e & 0xffff;
-        int predictor = block < 4 ? c.dc_y : block >= 6 ? c.dc_a : block == 4 ? c.dc_cr : c.dc_cb;
+        r.drop((int)(e >> 8));
+        const int size = (int)(e & 0xffu);
+        const int predictor = COMP == 0 ? c.dc_y : COMP == 3 ? c.dc_a : COMP == 1 ? c.dc_cr : c.dc_cb;
         int dc = predictor;
         if (size > 0) {
+            VLC_SYNC(r, c);
             const int differential = (int)r.get(size);
             dc = (differential & (1 << (size - 1))) ? predictor + differential
                                                     : predictor + ((int)(0xffffffffu << size) | (differential + 1));
         }
-        if (block < 4) c.dc_y = dc; else if (block >= 6) c.dc_a = dc; else if (block == 4) c.dc_cr = dc; else c.dc_cb = dc;
-        if ((int16_t)dc != 0) rec[1 + k++] = boff | (uint16_t)(int16_t)dc;
+        if (COMP == 0) c.dc_y = dc; else if (COMP == 3) c.dc_a = dc; else if (COMP == 1) c.dc_cr = dc; else c.dc_cb = dc;
+        if ((int16_t)dc != 0) rec[k++] = boff | (uint16_t)(int16_t)dc;
         n = 1;
     }
     bool first = n == 0;
     for (;;) {
+        VLC_SYNC(r, c);
         r.fill();
         const uint32_t p12 = (uint32_t)(r.w >> 52);
         uint32_t f = L.fast12[p12];
         // the first symbol of a block: '1s' is run 0, level +-1, and there is no end-of-block code
-        if (first && (p12 >> 11)) f = ((uint32_t)(uint16_t)(int16_t)(((p12 >> 10) & 1u) ? -1 : 1) << 16) | 2u;
+        if (first && (p12 >> 11)) f = ((p12 >> 10) & 1u ? 0xfc00u : 0x0400u) | 2u;
         first = false;
-        const int flen = (int)(f & 0x7fu);
+        const int flen = (int)(f & 0xfu);
         int run_len, level;
         if (flen) {
             r.drop(flen);
-            if (f & 0x80u) break;                             // end of block
-            run_len = (int)((f >> 8) & 0xffu);
-            level = (int)(int16_t)(f >> 16);
+            if (f & 0x10u) break;                             // end of block
+            run_len = (int)((f >> 5) & 31u);
+            level = (int)(int16_t)(uint16_t)f >> 10;
         } else {
             // longer codes and escapes
             const uint64_t w = r.w;
@@ -229,34 +291,47 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
         n += run_len;
         if (n > 63) return VLC_ERR_INDEX;
         const uint32_t zo = L.zz_off[n++];
-        if (level != 0) rec[1 + k++] = boff | (zo << 16) | (uint16_t)(int16_t)level;
+        if (level != 0) rec[k++] = boff | (zo << 16) | (uint16_t)(int16_t)level;
         if (r.pos > (uint32_t)(r.nd << 5)) return VLC_ERR_END;
     }
     if (k) {
-        rec[0] = (gid << 7) | (uint32_t)k;
-        c.out = rec + 1 + k;
-        atomicAdd(P.grp_cnt + gid, (uint32_t)k);
+        *c.hdr++ = (gid << 7) | (uint32_t)k;
+        c.ent = rec + k;
+        atomicAdd(reinterpret_cast<uint32_t*>(c.zbase + G.off_cnt) + gid, (uint32_t)k);
     }
     return 0;
 }
 
+__device__ __forceinline__ uint32_t vlc_mv_word(int h, int v) { return (uint32_t)(uint16_t)(int16_t)h | ((uint32_t)(uint16_t)(int16_t)v << 16); }
+
+// macroblock_address_increment: 1..33, 34 = stuffing, 35 = escape, -1 = invalid code
+__device__ __forceinline__ int vlc_mba(VlcWin& r, const VlcLds& L, VlcCtx& c)
+{
+    VLC_SYNC(r, c);
+    r.fill();
+    const uint32_t e = L.mba[r.peek(11)];
+    if (e == 0) return -1;
+    r.drop((int)(e >> 8));
+    return (int)(e & 0xffu);
+}
+
 // decoders/jsv.js:725-828 (+ B pictures), as decode_macroblock of leon_vlc.cpp.  0 = macroblock read, 1 = stop
 // silently (an address past the picture), > 1 an error
-__device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const VlcTables* __restrict__ T, const VlcGeom& G, const VlcPic& P,
-                                              VlcCtx& c, bool& slice_begin)
+__device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const VlcTables* __restrict__ T, const VlcGeom& G, VlcCtx& c,
+                                              bool& slice_begin)
 {
-    const int type = P.type, mbsize = G.mbw * G.mbh;
+    const int type = c.type, mbsize = G.mbw * G.mbh;
+    uint8_t* const m_qscale = reinterpret_cast<uint8_t*>(c.zbase + G.off_qscale);
+    uint8_t* const m_intra = reinterpret_cast<uint8_t*>(c.zbase + G.off_intra);
+    uint8_t* const m_repadd = reinterpret_cast<uint8_t*>(c.zbase + G.off_repadd);
+    uint8_t* const m_mb_dir = reinterpret_cast<uint8_t*>(c.zbase + G.off_mb_dir);
+    uint32_t* const m_mv_fwd = reinterpret_cast<uint32_t*>(c.zbase + G.off_mv_fwd);      // (h, v) int16 pairs as one word
+    uint32_t* const m_mv_bwd = reinterpret_cast<uint32_t*>(c.zbase + G.off_mv_bwd);
+
     int increment = 0, t;
-    auto mba = [&]() -> int {
-        r.fill();
-        const int32_t e = L.mba[r.peek(11)];
-        if (e == 0) return -1;
-        r.drop(e >> 16);
-        return e & 0xffff;
-    };
-    t = mba();
-    while (t == 34) t = mba();                               // stuffing
-    while (t == 35) { increment += 33; t = mba(); }          // escape
+    t = vlc_mba(r, L, c);
+    while (t == 34) t = vlc_mba(r, L, c);                    // stuffing
+    while (t == 35) { increment += 33; t = vlc_mba(r, L, c); }   // escape
     if (t < 0) return VLC_ERR_MBA + 1;
     increment += t;
     if (slice_begin) {
@@ -270,10 +345,10 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
         }
         while (increment > 1) {                              // skipped macroblocks
             const int a = ++c.mb_addr;
-            if (type != 1) *reinterpret_cast<uint32_t*>(P.mv_fwd + 2 * a) = (uint32_t)(uint16_t)(int16_t)c.fw_h | ((uint32_t)(uint16_t)(int16_t)c.fw_v << 16);
+            if (type != 1) m_mv_fwd[a] = vlc_mv_word(c.fw_h, c.fw_v);
             if (type == 3) {
-                *reinterpret_cast<uint32_t*>(P.mv_bwd + 2 * a) = (uint32_t)(uint16_t)(int16_t)c.bw_h | ((uint32_t)(uint16_t)(int16_t)c.bw_v << 16);
-                P.mb_dir[a] = (uint8_t)c.prev_dir;
+                m_mv_bwd[a] = vlc_mv_word(c.bw_h, c.bw_v);
+                m_mb_dir[a] = (uint8_t)c.prev_dir;
             }
             increment--;
         }
@@ -284,69 +359,81 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
     c.mb_col += mb - c.rc_addr;
     c.rc_addr = mb;
     while (c.mb_col >= G.mbw) { c.mb_col -= G.mbw; c.mb_row++; }
+    VLC_SYNC(r, c);
     r.fill();
-    const int32_t te = L.mbtype[type][r.peek(6)];
+    const uint32_t te = L.mbtype[type][r.peek(6)];
     if (te == 0) return VLC_ERR_TYPE + 1;
-    r.drop(te >> 16);
-    const int mb_type = te & 0xffff;
+    r.drop((int)(te >> 8));
+    const int mb_type = (int)(te & 0xffu);
     c.mb_intra = mb_type & 0x01;
     const int mot_fw = mb_type & 0x08, mot_bw = mb_type & 0x04;
-    if (mb_type & 0x10) c.qs = (int)r.get(5);
-    P.qscale[mb] = (uint8_t)c.qs;
-    P.intra[mb] = c.mb_intra ? 255 : 0;
+    if (mb_type & 0x10) c.qs = (int)r.get(5);                 // type (<= 6 bits) and quantiser_scale: one dword at most
+    m_qscale[mb] = (uint8_t)c.qs;
+    m_intra[mb] = c.mb_intra ? 255 : 0;
     if (c.mb_intra) {
         c.fw_h = c.fw_h_prev = 0; c.fw_v = c.fw_v_prev = 0;
         c.bw_h = c.bw_h_prev = 0; c.bw_v = c.bw_v_prev = 0;
         c.prev_dir = 0;
-        if (type != 1) P.repadd[mb] = 255;                   // jsv.js:1502-1505
+        if (type != 1) m_repadd[mb] = 255;                   // jsv.js:1502-1505
     } else {
         c.dc_y = c.dc_cr = c.dc_cb = c.dc_a = 128;
         int err = 0;
         if (mot_fw) {
-            c.fw_h_prev = vlc_motion_component(r, L, c.fw_h_prev, P.fwd_rsize, 1 << P.fwd_rsize, err);
-            c.fw_h = P.full_pel_fwd ? c.fw_h_prev * 2 : c.fw_h_prev;
-            c.fw_v_prev = vlc_motion_component(r, L, c.fw_v_prev, P.fwd_rsize, 1 << P.fwd_rsize, err);
-            c.fw_v = P.full_pel_fwd ? c.fw_v_prev * 2 : c.fw_v_prev;
+            VLC_SYNC(r, c);
+            c.fw_h_prev = vlc_motion_component(r, L, c.fw_h_prev, c.fwd_rsize, 1 << c.fwd_rsize, err);
+            c.fw_h = c.full_pel_fwd ? c.fw_h_prev * 2 : c.fw_h_prev;
+            VLC_SYNC(r, c);
+            c.fw_v_prev = vlc_motion_component(r, L, c.fw_v_prev, c.fwd_rsize, 1 << c.fwd_rsize, err);
+            c.fw_v = c.full_pel_fwd ? c.fw_v_prev * 2 : c.fw_v_prev;
         } else if (type == 2) {
             c.fw_h = c.fw_h_prev = 0;
             c.fw_v = c.fw_v_prev = 0;
         }
         if (mot_bw) {
-            c.bw_h_prev = vlc_motion_component(r, L, c.bw_h_prev, P.bwd_rsize, 1 << P.bwd_rsize, err);
-            c.bw_h = P.full_pel_bwd ? c.bw_h_prev * 2 : c.bw_h_prev;
-            c.bw_v_prev = vlc_motion_component(r, L, c.bw_v_prev, P.bwd_rsize, 1 << P.bwd_rsize, err);
-            c.bw_v = P.full_pel_bwd ? c.bw_v_prev * 2 : c.bw_v_prev;
+            VLC_SYNC(r, c);
+            c.bw_h_prev = vlc_motion_component(r, L, c.bw_h_prev, c.bwd_rsize, 1 << c.bwd_rsize, err);
+            c.bw_h = c.full_pel_bwd ? c.bw_h_prev * 2 : c.bw_h_prev;
+            VLC_SYNC(r, c);
+            c.bw_v_prev = vlc_motion_component(r, L, c.bw_v_prev, c.bwd_rsize, 1 << c.bwd_rsize, err);
+            c.bw_v = c.full_pel_bwd ? c.bw_v_prev * 2 : c.bw_v_prev;
         }
         if (err) return err + 1;
-        if (type != 1) *reinterpret_cast<uint32_t*>(P.mv_fwd + 2 * mb) = (uint32_t)(uint16_t)(int16_t)c.fw_h | ((uint32_t)(uint16_t)(int16_t)c.fw_v << 16);
+        if (type != 1) m_mv_fwd[mb] = vlc_mv_word(c.fw_h, c.fw_v);
         if (type == 3) {
-            *reinterpret_cast<uint32_t*>(P.mv_bwd + 2 * mb) = (uint32_t)(uint16_t)(int16_t)c.bw_h | ((uint32_t)(uint16_t)(int16_t)c.bw_v << 16);
+            m_mv_bwd[mb] = vlc_mv_word(c.bw_h, c.bw_v);
             c.prev_dir = (mot_fw ? 1 : 0) | (mot_bw ? 2 : 0);
-            P.mb_dir[mb] = (uint8_t)c.prev_dir;
+            m_mb_dir[mb] = (uint8_t)c.prev_dir;
         }
     }
     int cbp = 0;
+    VLC_SYNC(r, c);
     if (mb_type & 0x02) {
         r.fill();
-        const int32_t ce = L.cbp[r.peek(9)];
+        const uint32_t ce = L.cbp[r.peek(9)];
         if (ce == 0) return VLC_ERR_CBP + 1;
-        r.drop(ce >> 16);
-        cbp = ce & 0xffff;
+        r.drop((int)(ce >> 8));
+        cbp = (int)(ce & 0xffu);
     } else if (c.mb_intra) cbp = 0x3f;
     int apat = 0;
-    if (G.alpha) apat = c.mb_intra ? 0xf : (int)r.get(4);
-    for (int block = 0, mask = 0x20; block < 6; block++, mask >>= 1)
-        if (cbp & mask) { const int e = vlc_block(r, L, T, G, P, c, block); if (e) return e + 1; }
+    if (G.alpha) apat = c.mb_intra ? 0xf : (int)r.get(4);     // pattern (<= 9 bits) and alpha_pattern: one dword at most
+#pragma unroll 1
+    for (int block = 0, mask = 0x20; block < 4; block++, mask >>= 1)
+        if (cbp & mask) { const int e = vlc_block<0>(r, L, T, G, c, block); if (e) return e + 1; }
+    if (cbp & 0x2) { const int e = vlc_block<1>(r, L, T, G, c, 4); if (e) return e + 1; }
+    if (cbp & 0x1) { const int e = vlc_block<2>(r, L, T, G, c, 5); if (e) return e + 1; }
+#pragma unroll 1
     for (int block = 6, mask = 0x8; block < 10; block++, mask >>= 1)
-        if (apat & mask) { const int e = vlc_block(r, L, T, G, P, c, block); if (e) return e + 1; }
+        if (apat & mask) { const int e = vlc_block<3>(r, L, T, G, c, block); if (e) return e + 1; }
     return 0;
 }
 
 // LDS (36.75 KB per workgroup) allows four waves per SIMD: let the registers go that far too (128 VGPRs, no spills)
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_vlc_parse(const VlcSlice* __restrict__ slices, uint32_t* __restrict__ slice_words, int n_slices,
-                                                   const VlcPic* __restrict__ pics, VlcGeom G, const VlcTables* __restrict__ T)
+                                                   const VlcPic* __restrict__ pics, uint32_t* __restrict__ errors, VlcGeom G,
+                                                   const VlcTables* __restrict__ T)
 {
     __shared__ VlcLds L;
+    __shared__ __attribute__((aligned(16))) uint32_t rings[4 * kVlcRingDwords * 64];
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(T);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&L);
@@ -356,33 +443,47 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= n_slices) return;
     const VlcSlice S = slices[j];
-    const VlcPic P = pics[S.pic];
-    VlcWin r;
-    r.init(S.bytes, S.n_dwords, S.bit_pos);
     VlcCtx c{};
+    c.lane = threadIdx.x & 63;
+    c.wave_ring = rings + (threadIdx.x >> 6) * (kVlcRingDwords * 64);
+    VlcWin r;
+    r.init(S.bytes, S.n_dwords, S.bit_pos, c.wave_ring, c.lane);
+    {
+        const VlcPic* P = pics + S.pic;
+        c.zbase = P->zbase;
+        c.type = P->type;
+        c.full_pel_fwd = P->full_pel_fwd; c.fwd_rsize = P->fwd_rsize;
+        c.full_pel_bwd = P->full_pel_bwd; c.bwd_rsize = P->bwd_rsize;
+    }
     c.mb_addr = (S.code - 1) * G.mbw - 1;                     // decoders/jsv.js:683-706
     c.mb_row = S.code - 1;
     c.mb_col = -1;
     c.rc_addr = c.mb_addr;
     c.dc_y = c.dc_cr = c.dc_cb = c.dc_a = 128;
-    c.out = S.scratch;
-    c.out_end = S.scratch + S.scratch_cap;
+    c.hdr = S.scratch;
+    c.hdr_end = c.ent = S.scratch + S.hdr_cap;
+    c.ent_end = c.ent + S.ent_cap;
     c.qs = (int)r.get(5);
-    while (r.get(1) && r.pos < (S.end_byte << 3)) r.get(8);
+    for (;;) {                                                // extra_information_slice
+        VLC_SYNC(r, c);
+        if (!r.get(1) || r.pos >= (S.end_byte << 3)) break;
+        r.get(8);
+    }
     bool slice_begin = true;
     int err = 0;
     for (;;) {
-        const int rc = vlc_macroblock(r, L, T, G, P, c, slice_begin);       // 1: the reference's silent return, the loop goes on
+        const int rc = vlc_macroblock(r, L, T, G, c, slice_begin);       // 1: the reference's silent return, the loop goes on
         if (rc > 1) { err = rc - 1; break; }
         // next_bits_are_start_code (decoders/jsv.js:1710-1760): byte aligned 00 00 01, or the end of the data
+        VLC_SYNC(r, c);
         r.fill();
         const uint32_t i = (r.pos + 7u) >> 3, skip = (0u - r.pos) & 7u;
         if (i + 2u >= S.n_bytes) break;
         if ((uint32_t)((r.w << skip) >> 40) == 1u) break;
         if (i >= S.end_byte) { err = VLC_ERR_END; break; }    // behind the start code the host found: ran over it
     }
-    slice_words[j] = (uint32_t)(c.out - S.scratch);
-    if (err) atomicCAS(P.error, 0u, (uint32_t)err | ((uint32_t)S.code << 8));
+    slice_words[j] = (uint32_t)(c.hdr - S.scratch);           // coded blocks of the slice
+    if (err) atomicCAS(errors + S.pic, 0u, (uint32_t)err | ((uint32_t)S.code << 8));
 }
 
 // exclusive scan of a picture's group counters; the counters go back to zero (k_vlc_gather's cursors)
@@ -390,10 +491,11 @@ __global__ __launch_bounds__(256) void k_vlc_offsets(const VlcPic* __restrict__ 
 {
     __shared__ uint32_t part[256];
     const VlcPic P = pics[blockIdx.x];
+    uint32_t* const cnt = reinterpret_cast<uint32_t*>(P.zbase + G.off_cnt);
     const int ng = G.n_groups, per = (ng + 255) / 256;
     const int lo = min((int)threadIdx.x * per, ng), hi = min(lo + per, ng);
     uint32_t sum = 0;
-    for (int g = lo; g < hi; g++) sum += P.grp_cnt[g];
+    for (int g = lo; g < hi; g++) sum += cnt[g];
     part[threadIdx.x] = sum;
     __syncthreads();
     for (int d = 1; d < 256; d <<= 1) {                       // inclusive scan of the 256 partial sums
@@ -404,30 +506,43 @@ __global__ __launch_bounds__(256) void k_vlc_offsets(const VlcPic* __restrict__ 
     }
     uint32_t run = part[threadIdx.x] - sum;
     for (int g = lo; g < hi; g++) {
-        const uint32_t n = P.grp_cnt[g];
+        const uint32_t n = cnt[g];
         P.grp_off[g] = run;
-        P.grp_cnt[g] = 0;
+        cnt[g] = 0;
         run += n;
     }
     if (threadIdx.x == 255) P.grp_off[ng] = part[255];
 }
 
-__global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__ slices, const uint32_t* __restrict__ slice_words, int n_slices,
-                                                    const VlcPic* __restrict__ pics)
+__global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__ slices, const uint32_t* __restrict__ slice_blocks, int n_slices,
+                                                    const VlcPic* __restrict__ pics, VlcGeom G)
 {
-    const int j = blockIdx.x * 256 + threadIdx.x;
+    const int j = blockIdx.x * 4 + (int)(threadIdx.x >> 6);          // one wave per slice
+    const int lane = threadIdx.x & 63;
     if (j >= n_slices) return;
     const VlcSlice S = slices[j];
     const VlcPic P = pics[S.pic];
-    const uint32_t* rec = S.scratch;
-    const uint32_t* const end = rec + min(slice_words[j], S.scratch_cap);
-    while (rec < end) {
-        const uint32_t h = *rec++;
+    uint32_t* const cursor = reinterpret_cast<uint32_t*>(P.zbase + G.off_cnt);
+    const uint32_t n_blocks = min(slice_blocks[j], S.hdr_cap);
+    const uint32_t* const ent = S.scratch + S.hdr_cap;
+    uint32_t carry = 0;                                              // entries of the blocks before this round
+    for (uint32_t base = 0; base < n_blocks; base += 64) {
+        const uint32_t b = base + (uint32_t)lane;
+        const uint32_t h = b < n_blocks ? S.scratch[b] : 0u;
         const uint32_t gid = h >> 7, k = h & 127u;
-        const uint32_t at = P.grp_off[gid] + atomicAdd(P.grp_cnt + gid, k);
-        if (k > 64u || rec + k > end || at + k > P.entries_cap) break;        // cannot happen with k_vlc_parse's records
-        for (uint32_t i = 0; i < k; i++) P.entries[at + i] = rec[i];
-        rec += k;
+        uint32_t incl = k;                                           // inclusive prefix sum of k over the wave
+#pragma unroll
+        for (int d = 1; d < 64; d <<= 1) {
+            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
+            if (lane >= d) incl += up;
+        }
+        const uint32_t from = carry + incl - k;
+        carry += (uint32_t)__shfl((int)incl, 63, 64);
+        if (k != 0u && k <= 64u && from + k <= S.ent_cap) {
+            const uint32_t at = P.grp_off[gid] + atomicAdd(cursor + gid, k);
+            if (at + k <= P.entries_cap)
+                for (uint32_t i = 0; i < k; i++) P.entries[at + i] = ent[from + i];
+        }
     }
 }
 

@@ -1,0 +1,31 @@
+#!/bin/bash
+# Issue-side counters of the GPU parser's kernels (pipeline bench, gpu_parser), 3 counters per --pmc pass.
+cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
+out=${1:-gpurun_out/sq_vlc}
+mkdir -p $out
+S="python3 tools/pipeline_bench.py --loop 768 --threads 16 --window 256 --gpu-parser"
+i=0
+for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
+         "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
+         "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_SCA"; do
+  i=$((i+1)); timeout -k 10 200 rocprofv3 --pmc $c -d $out/p$i --output-format csv -- $S > $out/p$i.log 2>&1 || echo "pass $i ($c) failed"
+done
+python3 - $out <<'PY' > $out.txt
+import csv,glob,collections,sys
+pmc=collections.defaultdict(dict)
+for f in glob.glob(sys.argv[1]+"/**/*_counter_collection.csv",recursive=True):
+    agg=collections.defaultdict(lambda: collections.defaultdict(list))
+    for r in csv.DictReader(open(f)):
+        if "leon::k_vlc" not in r["Kernel_Name"]: continue
+        agg[r["Kernel_Name"].split("(")[0]][r["Counter_Name"]].append((int(r["Grid_Size"]),float(r["Counter_Value"])))
+    for k,cs in agg.items():
+        for c,vals in cs.items():
+            g=max(x for x,_ in vals); big=[v for x,v in vals if x==g]
+            pmc[k][c]=sum(big)/len(big)
+for k in sorted(pmc):
+    w=pmc[k].get("SQ_WAVES",1)
+    print(k, "waves", w)
+    print('   ', {c:round(v/w,1) for c,v in sorted(pmc[k].items())})
+PY
+rm -rf $out
+echo done
