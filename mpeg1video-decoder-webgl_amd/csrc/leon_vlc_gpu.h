@@ -41,9 +41,6 @@ struct VlcTables {
 };
 static constexpr int kVlcLdsWords = (4096 + 2048 + 2048 + 512 + 256 + 128 + 256 + 64) / 2;
 // every lane reads its slice through a ring of 16 dwords in LDS: dword i of lane L at ring[(i & 15) * 64 + L]
-#ifndef LEON_VLC_RING
-#define LEON_VLC_RING 1
-#endif
 static constexpr int kVlcRingDwords = 16;
 static constexpr int kVlcRingBytesPerWave = kVlcRingDwords * 64 * 4;
 
@@ -108,10 +105,8 @@ struct VlcWin {
         base = b; nd = n_dwords; pos = bit_pos;
         next = loaded = bit_pos >> 5;
         ring = wave_ring + lane;
-#if LEON_VLC_RING
         request(wave_ring, lane, next + kVlcRingDwords);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-#endif
         safe = loaded;
         const uint32_t lead = bit_pos & 31u;
         const uint32_t d0 = take(), d1 = take();
@@ -120,11 +115,7 @@ struct VlcWin {
     }
     __device__ __forceinline__ uint32_t take()
     {
-#if LEON_VLC_RING
         const uint32_t d = __builtin_bswap32(ring[(next & 15u) * 64u]);
-#else
-        const uint32_t d = next < nd ? __builtin_bswap32(__builtin_nontemporal_load(base + next)) : 0u;
-#endif
         next++;
         return d;
     }
@@ -133,9 +124,6 @@ struct VlcWin {
     // (requested half a ring ago), then request up to a full ring again.
     __device__ __forceinline__ void sync(uint32_t* wave_ring, int lane)
     {
-#if !LEON_VLC_RING
-        return;
-#endif
         const bool low = loaded - next < 8u || safe - next < 2u;
         if (__builtin_amdgcn_ballot_w64(low) != 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -211,6 +199,9 @@ __device__ __forceinline__ int vlc_motion_component(VlcWin& r, const VlcLds& L, 
 }
 
 // decoders/jsv.js:1338-1525 (decodeBlockGL), as decode_block of leon_vlc.cpp; returns an error code or 0
+// (All coded blocks of a macroblock in ONE loop -- an iteration = one symbol of whatever block the lane is in -- was
+// tried and is slower, 71 k against 95 k pictures/s end to end: a lane starts a block in almost every iteration of
+// the wave, so the block prologue is paid per symbol instead of six times per macroblock.)
 // COMP (which DC predictor, which DC table): 0 luma blocks 0..3, 1 block 4, 2 block 5, 3 the A blocks 6..9 -- a template
 // parameter: chosen at run time, the predictor would be read through a computed address and the whole context
 // would live in scratch memory
@@ -427,7 +418,7 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
     return 0;
 }
 
-// LDS (36.75 KB per workgroup) allows four waves per SIMD: let the registers go that far too (128 VGPRs, no spills)
+// LDS (tables 18.4 KB + four rings of 4 KB per workgroup) allows four waves per SIMD: let the registers go that far too
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_vlc_parse(const VlcSlice* __restrict__ slices, uint32_t* __restrict__ slice_words, int n_slices,
                                                    const VlcPic* __restrict__ pics, uint32_t* __restrict__ errors, VlcGeom G,
                                                    const VlcTables* __restrict__ T)

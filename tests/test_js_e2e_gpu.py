@@ -123,8 +123,9 @@ def test_addon_rejects_malformed_sparse_pictures():
     assert "repadd" in r[2]                       # a P picture without its maps
 
 
+@pytest.mark.parametrize("gpu_parser", [False, True], ids=["host-parser", "gpu-parser"])
 @pytest.mark.parametrize("name", ["leon_synth_352x240", "slices5_ip_96x64"])
-def test_native_pipeline_from_node_delivers_the_oracles_frames(name):
+def test_native_pipeline_from_node_delivers_the_oracles_frames(name, gpu_parser):
     """stream -> leon_pipeline_* (native threads) -> 'frames' events through a napi_threadsafe_function:
     every frame's RGBA equals the oracle's, in display order, and the JavaScript thread was never blocked
     (its 1 ms timer kept firing while the pipeline decoded)."""
@@ -133,8 +134,8 @@ def test_native_pipeline_from_node_delivers_the_oracles_frames(name):
     from test_pipeline_gpu import oracle_frames
     path = os.path.join(STREAMS, name + ".jsv")
     want = oracle_frames(open(path, "rb").read())
-    out = subprocess.run(["node", os.path.join(ROOT, "tools", "js_pipeline_bench.js"), path, "--hash", "--threads", "2", "--window", "1"],
-                         capture_output=True, text=True, timeout=600)
+    out = subprocess.run(["node", os.path.join(ROOT, "tools", "js_pipeline_bench.js"), path, "--hash", "--threads", "2", "--window", "1"] +
+                         (["--gpu-parser"] if gpu_parser else []), capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     got = json.loads(out.stdout.strip().splitlines()[-1])
     assert got["pictures"] == len(want) == len(got["frames"])
