@@ -21,8 +21,8 @@ def test_pmc_traffic_comes_from_the_committed_profile():
         path = os.path.join(ROOT, src.split(" ")[0])
         assert os.path.exists(path), path
         k = json.load(open(path))["kernels"]
-        name = "void leon::k_recon_display<%d, false>" if fused else "void leon::k_recon<%d, false>"
-        assert all(name % t in k for t in (1, 2, 3))
+        names = ("void leon::k_recon_display<%d, false, false>", "void leon::k_recon_display<%d, false>") if fused else ("void leon::k_recon<%d, false>",)
+        assert all(any(n % t in k for n in names) for t in (1, 2, 3))
         # fused display conversion: + RGBA of the 1080 displayed rows, - the planes of the B pictures
         rgba = 1024.0 * bench.FH / bench.CH if fused else 0.0
         b_planes = 384.0 if fused else 0.0

@@ -18,8 +18,9 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--pmc", nargs="*", default=[])
     ap.add_argument("--note", default="")
+    ap.add_argument("--out", default=os.path.join(ROOT, "profiles"), help="directory to write to (on the GPU box: somewhere under gpurun_out/)")
     a = ap.parse_args()
-    out = os.path.join(ROOT, "profiles")
+    out = a.out
     os.makedirs(out, exist_ok=True)
     if a.stats:
         f = glob.glob(os.path.join(a.stats, "**", "*_kernel_stats.csv"), recursive=True)[0]
