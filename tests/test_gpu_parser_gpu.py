@@ -80,3 +80,39 @@ def test_damaged_streams_are_refused(L):
             assert not clean or hi - lo == 1
         finally:
             pipe.close()
+
+
+def test_random_corruption_never_hangs_or_faults(L):
+    """40 seeded corruptions of a three-GOP stream (byte runs overwritten with random bytes, zeros or ones, inside the
+    second GOP's slice data): every run ends -- with frames or with an error -- and the next one starts on a clean
+    device; a run that completes delivers every frame of the untouched GOPs intact"""
+    import leon_vlc_ctypes as V
+    good = ibbp_stream(96, 64, [6, 6, 6], seed=9)
+    offs = V.Stream(good, threads=1).keymap()
+    clean, _, _ = run_pipeline(L, good, parser_threads=1, gops_per_window=3, gpu_parser=True, max_gop_pictures=64)
+    rng = np.random.default_rng(2026)
+    refused = 0
+    for case in range(40):
+        bad = bytearray(good)
+        lo = int(rng.integers(offs[1] + 40, offs[2] - 40))
+        n = int(rng.integers(1, 48))
+        kind = case % 3
+        for i in range(lo, min(lo + n, offs[2] - 8)):
+            bad[i] = int(rng.integers(0, 256)) if kind == 0 else (0 if kind == 1 else 0xFF)
+        got = {}
+
+        def on_window(window, frames):
+            for f in frames:
+                got[(f["gop"], f["display_index"])] = pipe.read_frame(f)
+        pipe = L.Pipeline(bytes(bad), gops_per_window=3, parser_threads=1, max_gop_pictures=64, gpu_parser=True, on_window=on_window)
+        try:
+            try:
+                pipe.wait()
+                for k, rgba in got.items():
+                    if k[0] != 1:
+                        assert np.array_equal(rgba, clean[k]), (case, k)
+            except L.LeonError:
+                refused += 1
+        finally:
+            pipe.close()
+    assert refused > 0
