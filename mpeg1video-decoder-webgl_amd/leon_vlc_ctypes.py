@@ -8,7 +8,21 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 SYMBOLS = ["leon_vlc_last_error", "leon_vlc_open", "leon_vlc_open_shard", "leon_vlc_close", "leon_vlc_get_info",
-           "leon_vlc_next_picture", "leon_vlc_next_picture_sync", "leon_vlc_seek", "leon_vlc_densify", "leon_vlc_densify_alpha", "leon_vlc_get_keymap"]
+           "leon_vlc_next_picture", "leon_vlc_next_picture_sync", "leon_vlc_seek", "leon_vlc_densify", "leon_vlc_densify_alpha", "leon_vlc_get_keymap",
+           "leon_vlc_scan_picture", "leon_vlc_get_gpu_tables"]
+
+
+class PictureScan(C.Structure):
+    _fields_ = [("type", C.c_int32), ("temporal_reference", C.c_int32), ("ts_ms", C.c_double), ("new_sequence", C.c_int32),
+                ("full_pel_fwd", C.c_int32), ("fwd_rsize", C.c_int32), ("full_pel_bwd", C.c_int32), ("bwd_rsize", C.c_int32),
+                ("n_slices", C.c_uint32), ("slice_code", C.POINTER(C.c_int32)), ("slice_bit_pos", C.POINTER(C.c_uint64)),
+                ("end_byte", C.c_uint64)]
+
+
+class GpuTables(C.Structure):
+    _fields_ = [("fast12", C.c_uint32 * 4096), ("coef16", C.c_int32 * 65536), ("motion_s", C.c_int32 * 2048), ("mba", C.c_int32 * 2048),
+                ("mbtype", (C.c_int32 * 64) * 4), ("cbp", C.c_int32 * 512), ("dc_lum", C.c_int32 * 128), ("dc_chr", C.c_int32 * 256),
+                ("zz_off", C.c_uint16 * 64)]
 
 
 class Info(C.Structure):
@@ -123,6 +137,21 @@ class Stream:
                     raise VlcError(self.lib.leon_vlc_last_error().decode())
                 out["coef_a"] = a
         return out
+
+    def scan_picture(self):
+        """leon_vlc_scan_picture: the next picture's header fields and slice positions (nothing below a slice start
+        code is read), or None at the end.  Not to be mixed with next_picture on one stream."""
+        p = PictureScan()
+        self.lib.leon_vlc_scan_picture.argtypes = [C.c_void_p, C.POINTER(PictureScan)]
+        rc = self.lib.leon_vlc_scan_picture(self.h, C.byref(p))
+        if rc < 0:
+            raise VlcError(self.lib.leon_vlc_last_error().decode())
+        if rc == 0:
+            return None
+        return {"type": p.type, "temporal_reference": p.temporal_reference, "ts": p.ts_ms, "new_sequence": bool(p.new_sequence),
+                "full_pel_fwd": p.full_pel_fwd, "fwd_rsize": p.fwd_rsize, "full_pel_bwd": p.full_pel_bwd, "bwd_rsize": p.bwd_rsize,
+                "slice_code": [int(p.slice_code[i]) for i in range(p.n_slices)],
+                "slice_bit_pos": [int(p.slice_bit_pos[i]) for i in range(p.n_slices)], "end_byte": int(p.end_byte)}
 
     def keymap(self):
         """byte offsets of the GOP shards (leon_vlc_get_keymap)"""

@@ -11,6 +11,8 @@ import os
 import shutil
 import subprocess
 
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -239,6 +241,53 @@ def test_gop_shards_parse_like_the_whole_stream(name):
         for k in ("coef_y", "coef_cb", "coef_cr", "repadd", "mv_fwd", "mv_bwd", "mb_dir"):
             if b.get(k) is not None:
                 assert np.array_equal(a[k], b[k]), (i, k)
+
+
+@pytest.mark.parametrize("name", ["leon_synth_352x240", "slices5_ip_96x64", "ibbp_96x64", "yuva_ibbp_96x64"])
+def test_scan_picture_finds_what_the_parser_parses(name):
+    """leon_vlc_scan_picture (the picture layer only, for the GPU parser): the same pictures in the same order as the
+    full parse, as many slices, every position right behind a slice start code whose code byte is the slice's"""
+    data = read(name)
+    _, whole = all_pictures(data, threads=1)
+    st = V.Stream(data, threads=1)
+    n = 0
+    while True:
+        sc = st.scan_picture()
+        if sc is None:
+            break
+        full = whole[n]
+        assert (sc["type"], sc["temporal_reference"]) == (full["type"], full["temporal_reference"])
+        assert len(sc["slice_code"]) == full["n_slices"] > 0
+        for code, pos in zip(sc["slice_code"], sc["slice_bit_pos"]):
+            assert pos % 8 == 0 and data[pos // 8 - 4:pos // 8] == bytes([0, 0, 1, code])
+        assert sc["slice_bit_pos"] == sorted(sc["slice_bit_pos"]) and sc["end_byte"] * 8 >= sc["slice_bit_pos"][-1]
+        assert data[sc["end_byte"]:sc["end_byte"] + 3] in (b"\x00\x00\x01", b"") or sc["end_byte"] >= len(data) - 3
+        n += 1
+    assert n == len(whole)
+
+
+def test_gpu_tables_are_the_parsers_tables():
+    """leon_vlc_get_gpu_tables: every entry decodes back to a code of the right length; the 12-bit coefficient table
+    agrees with the 16-bit one wherever it answers"""
+    t = V.GpuTables()
+    lib = V.load()
+    lib.leon_vlc_get_gpu_tables.argtypes = [C.POINTER(V.GpuTables)]
+    assert lib.leon_vlc_get_gpu_tables(C.byref(t)) == 0
+    fast, coef = np.array(t.fast12), np.array(t.coef16)
+    assert (fast[(np.arange(4096) >> 10) == 2] == (0x80 | 2)).all()                 # '10': end of block
+    for p in range(4096):
+        f = int(fast[p])
+        if f == 0 or (f & 0x80) or (p >> 10) == 3:
+            continue
+        e = int(coef[p << 4])
+        ln, cf = e >> 16, e & 0xffff
+        assert ln + 1 == (f & 0x7f) and (cf >> 8) == ((f >> 8) & 0xff), p
+        level = cf & 0xff
+        got = (f >> 16) - 65536 if (f >> 16) >= 32768 else (f >> 16)
+        assert got == (-level if (p >> (11 - ln)) & 1 else level), p
+    zz = np.array(t.zz_off)
+    assert sorted(zz.tolist()) == sorted(r * 128 + c * 2 for r in range(8) for c in range(8))
+    assert all(1 <= (int(e) & 0xffff) <= 35 and 1 <= (int(e) >> 16) <= 11 for e in np.array(t.mba) if e)
 
 
 def test_a_shard_keeps_its_last_macroblock():

@@ -22,7 +22,7 @@ let left = n, failed = false;
 const t0 = process.hrtime.bigint();
 for (let r = 0; r < n; r++) {
   const child = spawn(process.execPath, [bench, file, '--loop', String(opt('--loop', 0)), '--threads', String(opt('--threads', 0)),
-    '--window', String(opt('--window', 0)), '--device', String(oneDevice ? 0 : r), '--shard-index', String(r), '--shard-count', String(n)],
+    '--window', String(opt('--window', 0)), '--device', String(oneDevice ? 0 : r), '--shard-index', String(r), '--shard-count', String(n)].concat(process.argv.includes('--gpu-parser') ? ['--gpu-parser'] : []),
   { stdio: ['ignore', 'pipe', 'inherit'] });
   let out = '';
   child.stdout.on('data', (d) => { out += d; });
