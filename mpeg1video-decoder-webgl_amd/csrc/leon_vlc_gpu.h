@@ -200,8 +200,8 @@ __device__ __forceinline__ int vlc_motion_component(VlcWin& r, const VlcLds& L, 
 
 // decoders/jsv.js:1338-1525 (decodeBlockGL), as decode_block of leon_vlc.cpp; returns an error code or 0
 // (All coded blocks of a macroblock in ONE loop -- an iteration = one symbol of whatever block the lane is in -- was
-// tried and is slower, 71 k against 95 k pictures/s end to end: a lane starts a block in almost every iteration of
-// the wave, so the block prologue is paid per symbol instead of six times per macroblock.)
+// tried twice, the second time with a block start of a dozen instructions, and is slower both times: 71 k against
+// 93-95 k pictures/s end to end on one box.  The tight per-slot loop wins although it runs more iterations.)
 // COMP (which DC predictor, which DC table): 0 luma blocks 0..3, 1 block 4, 2 block 5, 3 the A blocks 6..9 -- a template
 // parameter: chosen at run time, the predictor would be read through a computed address and the whole context
 // would live in scratch memory
