@@ -75,6 +75,23 @@ struct VlcSlice {
 enum { VLC_ERR_MBA = 1, VLC_ERR_ADDR, VLC_ERR_TYPE, VLC_ERR_MOTION, VLC_ERR_CBP, VLC_ERR_COEF, VLC_ERR_INDEX, VLC_ERR_END, VLC_ERR_DC,
        VLC_ERR_SCRATCH };
 
+// Requests dwords [loaded, upto) of a lane's stream into its ring slots: 16 conditional LDS-direct loads, one per
+// slot (the LDS address of such a load is wave-uniform: slot i of every lane that wants it goes in one instruction).
+// NOT inlined: the top-up sits in front of every syntax element (28 places), and 28 copies of this made the kernel
+// four times as long as the instruction cache.
+__device__ __attribute__((noinline)) void vlc_request(const uint32_t* base, uint32_t loaded, uint32_t upto, uint32_t nd, uint32_t* wave_ring, int lane)
+{
+#pragma unroll
+    for (int i = 0; i < 16; i++) {
+        const uint32_t idx = loaded + (((uint32_t)i - loaded) & 15u);      // the dword >= loaded that lives in slot i
+        if (idx < upto) {
+            if (idx < nd) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + idx),
+                                                            (__attribute__((address_space(3))) void*)(wave_ring + i * 64), 4, 0, 0);
+            else wave_ring[i * 64 + lane] = 0u;
+        }
+    }
+}
+
 // The lane's view of its slice.  The stream does not come from memory symbol by symbol -- with 64 lanes in a wave some
 // lane would be waiting for a load at every step, and the wave with it -- but through the ring: the lanes top their
 // rings up TOGETHER (sync, below) with loads that go straight to LDS, half a ring ahead of what is being read, so
@@ -89,15 +106,7 @@ struct VlcWin {
     uint32_t* ring;              // this wave's ring (LDS), already offset by the lane
     __device__ __forceinline__ void request(uint32_t* wave_ring, int lane, uint32_t upto)      // dwords [loaded, upto), upto - next <= 16
     {
-#pragma unroll
-        for (int i = 0; i < kVlcRingDwords; i++) {
-            const uint32_t idx = loaded + (((uint32_t)i - loaded) & 15u);      // the dword >= loaded that lives in slot i
-            if (idx < upto) {
-                if (idx < nd) __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(base + idx),
-                                                                (__attribute__((address_space(3))) void*)(wave_ring + i * 64), 4, 0, 0);
-                else wave_ring[i * 64 + lane] = 0u;
-            }
-        }
+        vlc_request(base, loaded, upto, nd, wave_ring, lane);
         loaded = upto;
     }
     __device__ __forceinline__ void init(const uint32_t* b, uint32_t n_dwords, uint32_t bit_pos, uint32_t* wave_ring, int lane)
