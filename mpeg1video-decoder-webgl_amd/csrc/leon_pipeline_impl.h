@@ -379,7 +379,7 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
     w->n_vpics = (uint32_t)n_pics;
     if (!n_slices || !n_pics) return LEON_OK;
     VlcRing& R = p->vlc_ring[(size_t)w->ring];
-    const size_t desc_bytes = pad256(n_slices * sizeof(leon::VlcSlice)) + pad256(n_pics * sizeof(leon::VlcPic));
+    const size_t desc_bytes = pad256(n_slices * sizeof(leon::VlcSlice)) + pad256(n_pics * sizeof(leon::VlcPic)) + pad256(w->jobs.size() * sizeof(leon::VlcClear));
     const size_t dev_bytes = desc_bytes + pad256(n_slices * 4) + pad256(n_pics * 4);
     if (dev_bytes > R.cap) {                     // the ring entry is ours: its previous window has been released
         if (R.h) hipHostFree(R.h);
@@ -400,10 +400,13 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
     leon::VlcPic* hp = (leon::VlcPic*)(R.h + pad256(n_slices * sizeof(leon::VlcSlice)));
     uint32_t* d_words = (uint32_t*)(R.d + desc_bytes);
     uint32_t* d_err = (uint32_t*)(R.d + desc_bytes + pad256(n_slices * 4));
-    size_t si = 0, pi = 0;
+    leon::VlcClear* hc = (leon::VlcClear*)(R.h + pad256(n_slices * sizeof(leon::VlcSlice)) + pad256(n_pics * sizeof(leon::VlcPic)));
+    size_t si = 0, pi = 0, ci = 0;
     for (GopJob* job : w->jobs) {
-        // what the kernels count in and report through starts at zero
-        if (job->zero_bytes) HIP_TRY(hipMemsetAsync(job->arena->dev + job->zero_begin, 0, job->zero_bytes, p->vlc_stream));
+        // what the kernels count in and report through starts at zero (regions are multiples of 256 bytes)
+        hc[ci].ptr = (uint4*)(job->arena->dev + job->zero_begin);
+        hc[ci].n16 = job->zero_bytes / 16;
+        ci++;
         for (const leon::VlcSlice& sl : job->slices) {
             hs[si] = sl;
             hs[si].pic += (uint32_t)pi;
@@ -413,6 +416,8 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
     }
     HIP_TRY(hipMemcpyAsync(R.d, R.h, desc_bytes, hipMemcpyHostToDevice, p->vlc_stream));
     HIP_TRY(hipMemsetAsync(d_err, 0, n_pics * 4, p->vlc_stream));
+    const leon::VlcClear* dc = (const leon::VlcClear*)(R.d + pad256(n_slices * sizeof(leon::VlcSlice)) + pad256(n_pics * sizeof(leon::VlcPic)));
+    hipLaunchKernelGGL(leon::k_vlc_clear, dim3(32, (unsigned)w->jobs.size()), dim3(256), 0, p->vlc_stream, dc);
     const leon::VlcSlice* ds = (const leon::VlcSlice*)R.d;
     const leon::VlcPic* dp = (const leon::VlcPic*)(R.d + pad256(n_slices * sizeof(leon::VlcSlice)));
     const int blocks = (int)((n_slices + 255) / 256);

@@ -486,6 +486,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     if (err) atomicCAS(errors + S.pic, 0u, (uint32_t)err | ((uint32_t)S.code << 8));
 }
 
+// zeroes the regions the parser counts in and reports through (one per GOP of the window: the arenas are separate
+// allocations), 16 bytes per thread and round -- one launch instead of a fill per GOP
+struct VlcClear { uint4* ptr; uint64_t n16; };
+__global__ __launch_bounds__(256) void k_vlc_clear(const VlcClear* __restrict__ regions)
+{
+    const VlcClear R = regions[blockIdx.y];
+    for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < R.n16; i += (uint64_t)gridDim.x * 256) R.ptr[i] = uint4{0u, 0u, 0u, 0u};
+}
+
 // exclusive scan of a picture's group counters; the counters go back to zero (k_vlc_gather's cursors)
 __global__ __launch_bounds__(256) void k_vlc_offsets(const VlcPic* __restrict__ pics, VlcGeom G)
 {
