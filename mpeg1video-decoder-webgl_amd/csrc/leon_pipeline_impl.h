@@ -110,7 +110,7 @@ struct leon_pipeline {
 
     // stats
     Clock::time_point t0;
-    std::atomic<uint64_t> st_pictures{0}, st_gops{0}, st_entries{0}, st_parse_ns{0}, st_upload{0};
+    std::atomic<uint64_t> st_pictures{0}, st_gops{0}, st_entries{0}, st_parse_ns{0}, st_upload{0}, st_submit_ns{0}, st_submit_wait_ns{0};
     double st_seconds = 0;
 };
 
@@ -614,7 +614,9 @@ void submit_loop(leon_pipeline* p)
         if (rc == LEON_OK) {
             if (hipEventCreateWithFlags(&w->done, hipEventDisableTiming) != hipSuccess) { rc = LEON_ERR_HIP; msg = "hipEventCreate failed"; }
             else {
+                const auto t = Clock::now();
                 rc = submit_window(p, w);
+                p->st_submit_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t).count();
                 if (rc != LEON_OK) msg = g_err;
             }
         }
@@ -938,6 +940,9 @@ void leon_pipeline_destroy(leon_pipeline* p)
         if (a->dev) hipFree(a->dev);
         delete a;
     }
+    if (getenv("LEON_DEBUG_PIPE_TIMING"))      // where the submit thread's time went (LEON_DEBUG_PIPE_TIMING=1)
+        fprintf(stderr, "leon pipeline: %llu windows, submit_window %.1f ms per window on the host\n", (unsigned long long)p->windows_submitted,
+                p->windows_submitted ? (double)p->st_submit_ns.load() / 1e6 / (double)p->windows_submitted : 0.0);
     for (VlcRing& r : p->vlc_ring) {
         if (r.h) hipHostFree(r.h);
         if (r.d) hipFree(r.d);
