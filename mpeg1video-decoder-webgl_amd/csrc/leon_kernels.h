@@ -508,14 +508,14 @@ __device__ __forceinline__ uint32_t pred_x256(uint32_t pred)
 // decomposition, quantiser tables, the in-picture test -- is computed once per task.
 
 // Fused display conversion (DISPLAY): the picture leaves the kernel as RGBA8 as well -- the CPU twin of
-// the reference's conversion, same fp64 operations in the same order as k_rgba_twin4 below -- so the
-// planes of a picture nobody predicts from (B pictures: 8 of 12 in IBBP) are never written and never
+// the reference's conversion, bit for bit what k_rgba_twin4 below computes in fp64 (here from exact fixed-point
+// tables, see rgba_px) -- so the planes of a picture nobody predicts from (B pictures: 8 of 12 in IBBP) are never written and never
 // read back, and the others are not read back.  A task then covers 8 macroblocks completely: first the
 // chroma part (CHROMA = true: the Cb and Cr groups, whose samples are parked in an LDS stash), then the
 // two luma parts (CHROMA = false, 4 macroblocks each), whose lanes hold 8 horizontally adjacent Y samples
 // and find their 4 Cb and 4 Cr samples in the stash.
 struct Display {
-    char* stash;                 // LDS: [Cb | Cr][8 rows][64 bytes], then the parked Y rows of a luma part's upper half
+    char* stash;                 // LDS: [Cb | Cr][8 rows][64 bytes]
     int side;                    // luma parts: 0 / 1 = left / right four macroblocks of the chroma group
     char* apark;                 // yuva: the A samples of the four macroblocks, [half][8 rows][64 bytes]
     const char* lut;             // LDS copy of Tables::rgba_lut (the workgroup's)
