@@ -91,7 +91,7 @@ const path = require('path'), crypto = require('crypto');
 const { LeonPlayer } = require(path.join(%(js)r, 'leon_player.js'));
 const backend = require(path.join(%(js)r, '..', 'napi', 'leon_napi.node'));
 const ev = [], shown = [];
-const p = new LeonPlayer({ backend, pipeline: true, realtime: false, parserThreads: 2,
+const p = new LeonPlayer({ backend, pipeline: true, realtime: false, parserThreads: 2, gpuParser: %(gpu_parser)s,
   render: (rgba, f) => shown.push({ gop: f.gop, di: f.displayIndex, ts: f.ts, sha: crypto.createHash('sha256').update(rgba).digest('hex') }) });
 for (const e of ['loadstart', 'loadedmetadata', 'loadeddata', 'canplay', 'play', 'playing', 'seeking', 'seeked', 'ended', 'error']) p.on(e, () => ev.push(e));
 let phase = 0;
@@ -106,14 +106,15 @@ p.play();
 
 
 @pytest.mark.gpu
-def test_player_over_the_native_pipeline():
+@pytest.mark.parametrize("gpu_parser", [False, True], ids=["host-parser", "gpu-parser"])
+def test_player_over_the_native_pipeline(gpu_parser):
     """the HTML5-video-shaped surface with the native pipeline underneath: same events, frames in display order with
     the oracle's pixels, a seek restarts at the key-map entry for the time"""
     import hashlib
     from test_pipeline_gpu import oracle_frames
     path = os.path.join(STREAMS, "leon_synth_352x240.jsv")
     want = oracle_frames(open(path, "rb").read())
-    out = subprocess.run(["node", "-e", _PIPE_SCRIPT % {"js": JSDIR, "stream": path, "seek": "0.6"}], capture_output=True, text=True, timeout=300)
+    out = subprocess.run(["node", "-e", _PIPE_SCRIPT % {"js": JSDIR, "stream": path, "seek": "0.6", "gpu_parser": "true" if gpu_parser else "false"}], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr[-3000:]
     r = json.loads(out.stdout.strip().splitlines()[-1])
     assert (r["w"], r["h"]) == (352, 240) and "error" not in r["ev"]

@@ -191,14 +191,15 @@ def test_pipeline_errors(L):
         pipe.close()
 
 
-def test_gop_shards_partition_the_stream(L):
+@pytest.mark.parametrize("gpu_parser", [False, True], ids=["host-parser", "gpu-parser"])
+def test_gop_shards_partition_the_stream(L, gpu_parser):
     """two pipelines with shard_index 0 / 1 of 2 (one per GPU on a node; both on this box's device here)
     decode disjoint GOP sets whose union is the whole stream, frames keyed by the stream's GOP ids"""
     data = ibbp_stream(96, 64, [6, 9, 3, 12, 6], seed=31)
     want = oracle_frames(data)
     got = {}
     for r in range(2):
-        part, _, stats = run_pipeline(L, data, parser_threads=2, gops_per_window=2, shard_index=r, shard_count=2)
+        part, _, stats = run_pipeline(L, data, parser_threads=2, gops_per_window=2, shard_index=r, shard_count=2, gpu_parser=gpu_parser)
         assert {g for g, _ in part} == {g for g in range(5) if g % 2 == r}
         assert not set(part) & set(got)
         got.update(part)
