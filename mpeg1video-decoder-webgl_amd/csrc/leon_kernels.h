@@ -370,14 +370,16 @@ __device__ __forceinline__ int handoff16(int w)
 
 // ---- motion-compensated prediction of 8 horizontally adjacent samples ------
 
-// exact (a+b+c+d+2)>>2 on 4 packed bytes: three rounded-up averages and one fix-up
+// exact (a+b+c+d+2)>>2 on 4 packed bytes in three v_lerp_u8 (per byte (p + q + (r & 1)) >> 1: the third operand is a
+// per-byte rounding bit) and one xor.  With sa = a+b = 2x+rx, sc = c+d = 2y+ry:
+//   (sa + sc + 2) >> 2 = (x + y + 1 + (rx & ry)) >> 1,   and   (a + b + ry) >> 1 = x + (rx & ry)   (ry = LSB of c ^ d)
+// so X = lerp(a, b, c ^ d), y = lerp(c, d, 0), result = lerp(X, y, 1).  (Round 1 had three rounded-up averages and a
+// five-instruction fix-up: twice the instructions.)
 __device__ __forceinline__ uint32_t avg4_u8x4(uint32_t a, uint32_t b, uint32_t c, uint32_t d)
 {
-    const uint32_t ones = 0x01010101u;
-    uint32_t x = __builtin_amdgcn_lerp(a, b, ones);
-    uint32_t y = __builtin_amdgcn_lerp(c, d, ones);
-    uint32_t r = __builtin_amdgcn_lerp(x, y, ones);
-    return r - (((a ^ b) | (c ^ d)) & (x ^ y) & ones);
+    const uint32_t X = __builtin_amdgcn_lerp(a, b, c ^ d);
+    const uint32_t y = __builtin_amdgcn_lerp(c, d, 0u);
+    return __builtin_amdgcn_lerp(X, y, 0x01010101u);
 }
 
 // reference texel addressing: sample x lives in RGBA texel x>>2, component x&3; the
