@@ -661,7 +661,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
         const uint32_t nY = 2u * (uint32_t)G.tasksY, nC = (uint32_t)G.tasksC;
         const uint32_t gid0 = CHROMA ? nY + (uint32_t)(Rt * G.gC + g) : (uint32_t)(2 * Rt * G.gY + g) + (alpha ? nY + 2u * nC : 0u);
         const uint32_t gid1 = CHROMA ? gid0 + nC : gid0 + (uint32_t)G.gY;
-        const uint32_t* go = pd.grp_off;                     // wave-uniform index: scalar loads
+        const LEON_GLOBAL uint32_t* go = gptr(pd.grp_off);    // wave-uniform index; global, not flat: a flat load counts on the LDS counter too
         const uint32_t gid[2] = {gid0, gid1};
 #pragma unroll
         for (int h = 0; h < 2; h++) {

@@ -26,6 +26,11 @@
 
 namespace leon {
 
+// Pointers into device memory are told to be GLOBAL: through a generic pointer every store is a flat_store, which
+// counts on the LDS counter too -- and the wait in front of the next table lookup (LDS) then waits for the entry
+// stored a symbol earlier to reach memory.
+#define VLC_G __attribute__((address_space(1)))
+
 // Device copy of the front end's tables (leon_vlc_get_gpu_tables), the LDS part first and in 16 bits:
 //   fast12: bits 0..3 length (0 = longer code or escape), bit 4 end of block, bits 5..9 run, bits 10..15 level
 //   the others: (length << 8) | value, 0 = invalid code
@@ -176,11 +181,11 @@ struct VlcCtx {                  // per lane: the state a slice carries from mac
     int fw_h, fw_v, fw_h_prev, fw_v_prev, bw_h, bw_v, bw_h_prev, bw_v_prev, prev_dir;
     int dc_y, dc_cr, dc_cb, dc_a, qs;
     int mb_intra;
-    uint32_t* hdr;               // next free block header of the scratch strip
-    uint32_t* ent;               // next free entry
-    uint32_t* hdr_end;
-    uint32_t* ent_end;
-    char* zbase;                 // the picture's counters and maps
+    VLC_G uint32_t* hdr;         // next free block header of the scratch strip
+    VLC_G uint32_t* ent;         // next free entry
+    VLC_G uint32_t* hdr_end;
+    VLC_G uint32_t* ent_end;
+    VLC_G char* zbase;           // the picture's counters and maps
     int type, full_pel_fwd, fwd_rsize, full_pel_bwd, bwd_rsize;
     uint32_t* wave_ring;         // LDS ring of the wave (VlcWin::sync)
     int lane;
@@ -229,7 +234,7 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
     }
     const uint32_t boff = (bq * 16u) << 16;
     if (c.hdr >= c.hdr_end || c.ent + 64 > c.ent_end) return VLC_ERR_SCRATCH;      // a block: one header, at most 64 entries
-    uint32_t* const rec = c.ent;
+    VLC_G uint32_t* const rec = c.ent;
     int k = 0, n = 0;
     if (c.mb_intra) {
         VLC_SYNC(r, c);
@@ -269,7 +274,7 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
         } else {
             // longer codes and escapes
             const uint64_t w = r.w;
-            const int32_t e = T->coef16[w >> 48];
+            const int32_t e = ((const VLC_G int32_t*)T->coef16)[w >> 48];
             if (e == 0) return VLC_ERR_COEF;
             const int len = e >> 16, coeff = e & 0xffff;
             int used;
@@ -297,7 +302,7 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
     if (k) {
         *c.hdr++ = (gid << 7) | (uint32_t)k;
         c.ent = rec + k;
-        atomicAdd(reinterpret_cast<uint32_t*>(c.zbase + G.off_cnt) + gid, (uint32_t)k);
+        __hip_atomic_fetch_add(reinterpret_cast<VLC_G uint32_t*>(c.zbase + G.off_cnt) + gid, (uint32_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return 0;
 }
@@ -321,12 +326,12 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
                                               bool& slice_begin)
 {
     const int type = c.type, mbsize = G.mbw * G.mbh;
-    uint8_t* const m_qscale = reinterpret_cast<uint8_t*>(c.zbase + G.off_qscale);
-    uint8_t* const m_intra = reinterpret_cast<uint8_t*>(c.zbase + G.off_intra);
-    uint8_t* const m_repadd = reinterpret_cast<uint8_t*>(c.zbase + G.off_repadd);
-    uint8_t* const m_mb_dir = reinterpret_cast<uint8_t*>(c.zbase + G.off_mb_dir);
-    uint32_t* const m_mv_fwd = reinterpret_cast<uint32_t*>(c.zbase + G.off_mv_fwd);      // (h, v) int16 pairs as one word
-    uint32_t* const m_mv_bwd = reinterpret_cast<uint32_t*>(c.zbase + G.off_mv_bwd);
+    VLC_G uint8_t* const m_qscale = reinterpret_cast<VLC_G uint8_t*>(c.zbase + G.off_qscale);
+    VLC_G uint8_t* const m_intra = reinterpret_cast<VLC_G uint8_t*>(c.zbase + G.off_intra);
+    VLC_G uint8_t* const m_repadd = reinterpret_cast<VLC_G uint8_t*>(c.zbase + G.off_repadd);
+    VLC_G uint8_t* const m_mb_dir = reinterpret_cast<VLC_G uint8_t*>(c.zbase + G.off_mb_dir);
+    VLC_G uint32_t* const m_mv_fwd = reinterpret_cast<VLC_G uint32_t*>(c.zbase + G.off_mv_fwd);      // (h, v) int16 pairs as one word
+    VLC_G uint32_t* const m_mv_bwd = reinterpret_cast<VLC_G uint32_t*>(c.zbase + G.off_mv_bwd);
 
     int increment = 0, t;
     t = vlc_mba(r, L, c);
@@ -450,7 +455,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     r.init(S.bytes, S.n_dwords, S.bit_pos, c.wave_ring, c.lane);
     {
         const VlcPic* P = pics + S.pic;
-        c.zbase = P->zbase;
+        c.zbase = (VLC_G char*)P->zbase;
         c.type = P->type;
         c.full_pel_fwd = P->full_pel_fwd; c.fwd_rsize = P->fwd_rsize;
         c.full_pel_bwd = P->full_pel_bwd; c.bwd_rsize = P->bwd_rsize;
@@ -460,8 +465,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     c.mb_col = -1;
     c.rc_addr = c.mb_addr;
     c.dc_y = c.dc_cr = c.dc_cb = c.dc_a = 128;
-    c.hdr = S.scratch;
-    c.hdr_end = c.ent = S.scratch + S.hdr_cap;
+    c.hdr = (VLC_G uint32_t*)S.scratch;
+    c.hdr_end = c.ent = c.hdr + S.hdr_cap;
     c.ent_end = c.ent + S.ent_cap;
     c.qs = (int)r.get(5);
     for (;;) {                                                // extra_information_slice
@@ -482,8 +487,8 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if ((uint32_t)((r.w << skip) >> 40) == 1u) break;
         if (i >= S.end_byte) { err = VLC_ERR_END; break; }    // behind the start code the host found: ran over it
     }
-    slice_words[j] = (uint32_t)(c.hdr - S.scratch);           // coded blocks of the slice
-    if (err) atomicCAS(errors + S.pic, 0u, (uint32_t)err | ((uint32_t)S.code << 8));
+    ((VLC_G uint32_t*)slice_words)[j] = (uint32_t)(c.hdr - (VLC_G uint32_t*)S.scratch);       // coded blocks of the slice
+    if (err) atomicCAS(errors + S.pic, 0u, (uint32_t)err | ((uint32_t)S.code << 8));     // rare: a generic atomic is fine here
 }
 
 // zeroes the regions the parser counts in and reports through (one per GOP of the window: the arenas are separate
@@ -531,13 +536,16 @@ __global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__
     if (j >= n_slices) return;
     const VlcSlice S = slices[j];
     const VlcPic P = pics[S.pic];
-    uint32_t* const cursor = reinterpret_cast<uint32_t*>(P.zbase + G.off_cnt);
+    VLC_G uint32_t* const cursor = reinterpret_cast<VLC_G uint32_t*>((VLC_G char*)P.zbase + G.off_cnt);
     const uint32_t n_blocks = min(slice_blocks[j], S.hdr_cap);
-    const uint32_t* const ent = S.scratch + S.hdr_cap;
+    const VLC_G uint32_t* const hdr = (const VLC_G uint32_t*)S.scratch;
+    const VLC_G uint32_t* const ent = hdr + S.hdr_cap;
+    const VLC_G uint32_t* const grp_off = (const VLC_G uint32_t*)P.grp_off;
+    VLC_G uint32_t* const entries = (VLC_G uint32_t*)P.entries;
     uint32_t carry = 0;                                              // entries of the blocks before this round
     for (uint32_t base = 0; base < n_blocks; base += 64) {
         const uint32_t b = base + (uint32_t)lane;
-        const uint32_t h = b < n_blocks ? S.scratch[b] : 0u;
+        const uint32_t h = b < n_blocks ? hdr[b] : 0u;
         const uint32_t gid = h >> 7, k = h & 127u;
         uint32_t incl = k;                                           // inclusive prefix sum of k over the wave
 #pragma unroll
@@ -548,9 +556,9 @@ __global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__
         const uint32_t from = carry + incl - k;
         carry += (uint32_t)__shfl((int)incl, 63, 64);
         if (k != 0u && k <= 64u && from + k <= S.ent_cap) {
-            const uint32_t at = P.grp_off[gid] + atomicAdd(cursor + gid, k);
+            const uint32_t at = grp_off[gid] + __hip_atomic_fetch_add(cursor + gid, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (at + k <= P.entries_cap)
-                for (uint32_t i = 0; i < k; i++) P.entries[at + i] = ent[from + i];
+                for (uint32_t i = 0; i < k; i++) entries[at + i] = ent[from + i];
         }
     }
 }
