@@ -255,15 +255,23 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
         if ((int16_t)dc != 0) rec[k++] = boff | (uint16_t)(int16_t)dc;
         n = 1;
     }
-    bool first = n == 0;
+    // the first symbol of a non-intra block: '1s' is run 0, level +-1 (two bits), and there is no end-of-block code.
+    // Every other first symbol starts with a 0 bit and reads like any later one: only this case is handled here, in
+    // front of the loop (inside it, the test cost every iteration six instructions).
+    if (n == 0) {
+        VLC_SYNC(r, c);
+        r.fill();
+        const uint32_t p2 = r.peek(2);
+        if (p2 & 2u) {
+            r.drop(2);
+            rec[k++] = boff | (uint32_t)(uint16_t)(int16_t)((p2 & 1u) ? -1 : 1);      // zig-zag position 0: tile offset 0
+            n = 1;
+        }
+    }
     for (;;) {
         VLC_SYNC(r, c);
         r.fill();
-        const uint32_t p12 = (uint32_t)(r.w >> 52);
-        uint32_t f = L.fast12[p12];
-        // the first symbol of a block: '1s' is run 0, level +-1, and there is no end-of-block code
-        if (first && (p12 >> 11)) f = ((p12 >> 10) & 1u ? 0xfc00u : 0x0400u) | 2u;
-        first = false;
+        const uint32_t f = L.fast12[(uint32_t)(r.w >> 52)];
         const int flen = (int)(f & 0xfu);
         int run_len, level;
         if (flen) {
@@ -297,8 +305,8 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
         if (n > 63) return VLC_ERR_INDEX;
         const uint32_t zo = L.zz_off[n++];
         if (level != 0) rec[k++] = boff | (zo << 16) | (uint16_t)(int16_t)level;
-        if (r.pos > (uint32_t)(r.nd << 5)) return VLC_ERR_END;
     }
+    if (r.pos > (uint32_t)(r.nd << 5)) return VLC_ERR_END;     // ran off the data (zeros behind it: an invalid code ended the loop at the latest)
     if (k) {
         *c.hdr++ = (gid << 7) | (uint32_t)k;
         c.ent = rec + k;
