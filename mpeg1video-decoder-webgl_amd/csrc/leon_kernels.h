@@ -988,8 +988,11 @@ __global__ __launch_bounds__(kReconMaxThreads) void k_recon(const PicDesc* __res
 // The same reconstruction with the display conversion fused in (see Display above).  One wave = the 8
 // macroblocks of one chroma group, all components: tasks_per_pic = tasksC here (the host sets Geom up
 // for that), the chroma part first, then the left and the right luma part.
+// The sparse B kernel (what the pipeline runs most) is held to 72 registers = 7 waves per SIMD: it wants 74, the two
+// spilled dwords (8 bytes of scratch per lane) cost less than the wave brings: +1..2 % end to end, three pairs on one box.
 template <int TYPE, bool SPARSE, bool ALPHA = false>
-__global__ __launch_bounds__(kReconMaxThreads) void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
+__global__ __launch_bounds__(kReconMaxThreads) __attribute__((amdgpu_waves_per_eu(TYPE == 3 && SPARSE && !ALPHA ? 7 : 4)))
+void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
                                                                     const Tables* __restrict__ T)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];

@@ -18,7 +18,7 @@ BUDGET = {
     "k_reconILi1ELb0E": 64, "k_reconILi2ELb0E": 64, "k_reconILi3ELb0E": 72,
     "k_reconILi1ELb1E": 64, "k_reconILi2ELb1E": 64, "k_reconILi3ELb1E": 72,
     "k_recon_displayILi1ELb0ELb0E": 64, "k_recon_displayILi2ELb0ELb0E": 64, "k_recon_displayILi3ELb0ELb0E": 72,
-    "k_recon_displayILi1ELb1ELb0E": 64, "k_recon_displayILi2ELb1ELb0E": 64, "k_recon_displayILi3ELb1ELb0E": 80,
+    "k_recon_displayILi1ELb1ELb0E": 64, "k_recon_displayILi2ELb1ELb0E": 64, "k_recon_displayILi3ELb1ELb0E": (72, 8),    # held to 7 waves: 8 bytes of scratch
     # yuva (A part + Y part per side): one occupancy step below the three-component kernels
     "k_recon_displayILi1ELb0ELb1E": 64, "k_recon_displayILi2ELb0ELb1E": 72, "k_recon_displayILi3ELb0ELb1E": 88,
     "k_recon_displayILi1ELb1ELb1E": 64, "k_recon_displayILi2ELb1ELb1E": 72, "k_recon_displayILi3ELb1ELb1E": 88,
@@ -50,5 +50,6 @@ def test_register_budgets_and_no_scratch(tmp_path):
         hit = [(n, v) for n, v in seen.items() if key in n]
         assert hit, "kernel %s not found in the resource report" % key
         name, v = hit[0]
-        assert v["scratch"] == 0, "%s spills %d bytes per lane" % (name, v["scratch"])
+        limit, scratch = limit if isinstance(limit, tuple) else (limit, 0)
+        assert v["scratch"] <= scratch, "%s spills %d bytes per lane" % (name, v["scratch"])
         assert v["vgpr"] <= limit, "%s uses %d VGPRs, budget %d" % (name, v["vgpr"], limit)
