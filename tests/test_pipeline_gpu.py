@@ -210,7 +210,8 @@ def test_gop_shards_partition_the_stream(L, gpu_parser):
         L.Pipeline(data, shard_index=7, shard_count=8)       # more shards than GOPs: this one would be empty
 
 
-def test_destroy_while_running_and_with_windows_held(L):
+@pytest.mark.parametrize("gpu_parser", [False, True], ids=["host-parser", "gpu-parser"])
+def test_destroy_while_running_and_with_windows_held(L, gpu_parser):
     """tearing a pipeline down mid-run -- parsers busy, windows in flight, windows delivered and never released --
     joins every thread and frees everything (no callback after close returns)"""
     data = ibbp_stream(96, 64, [6] * 8, seed=5)
@@ -218,7 +219,7 @@ def test_destroy_while_running_and_with_windows_held(L):
         for _ in range(3):
             seen = []
             pipe = L.Pipeline(data, on_window=lambda w, fr: (seen.append(w), False if hold else None)[1],
-                              parser_threads=3, gops_per_window=2, windows_in_flight=2, loop=50)
+                              parser_threads=3, gops_per_window=2, windows_in_flight=2, loop=50, gpu_parser=gpu_parser)
             import time
             time.sleep(0.02)
             pipe.close()
@@ -226,5 +227,5 @@ def test_destroy_while_running_and_with_windows_held(L):
             time.sleep(0.05)
             assert len(seen) == n            # nothing arrives after close
     # and a normal run still works afterwards
-    got, _, stats = run_pipeline(L, data, parser_threads=2, gops_per_window=4)
+    got, _, stats = run_pipeline(L, data, parser_threads=2, gops_per_window=4, gpu_parser=gpu_parser)
     assert stats["gops"] == 8 and len(got) == 48
