@@ -563,11 +563,21 @@ __global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__
         }
         const uint32_t from = carry + incl - k;
         carry += (uint32_t)__shfl((int)incl, 63, 64);
-        if (k != 0u && k <= 64u && from + k <= S.ent_cap) {
-            const uint32_t at = grp_off[gid] + __hip_atomic_fetch_add(cursor + gid, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (at + k <= P.entries_cap)
-                for (uint32_t i = 0; i < k; i++) entries[at + i] = ent[from + i];
-        }
+        // Neighbouring lanes often hold the two blocks of one macroblock that lie in the same group (Y0 Y1, Y2 Y3):
+        // such a pair takes ONE atomic add -- the launch is bound by their rate.  A lane follows its left neighbour
+        // when both have entries for the same group and the neighbour does not follow somebody itself.
+        const uint32_t gid_l = (uint32_t)__shfl_up((int)gid, 1, 64), k_l = (uint32_t)__shfl_up((int)k, 1, 64);
+        const bool same_l = lane > 0 && k != 0u && k_l != 0u && gid_l == gid;
+        const bool follows = same_l && !__shfl_up((int)same_l, 1, 64);
+        const bool followed = __shfl_down((int)follows, 1, 64) != 0 && lane < 63;
+        const uint32_t k_r = (uint32_t)__shfl_down((int)k, 1, 64);
+        const bool ok = k != 0u && k <= 64u && from + k <= S.ent_cap;
+        uint32_t at = 0u;
+        if (ok && !follows) at = grp_off[gid] + __hip_atomic_fetch_add(cursor + gid, followed ? k + k_r : k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const uint32_t at_l = (uint32_t)__shfl_up((int)at, 1, 64);
+        if (follows) at = at_l + k_l;
+        if (ok && at + k <= P.entries_cap)
+            for (uint32_t i = 0; i < k; i++) entries[at + i] = ent[from + i];
     }
 }
 
