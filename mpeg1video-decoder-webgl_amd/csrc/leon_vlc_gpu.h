@@ -539,7 +539,9 @@ __global__ __launch_bounds__(256) void k_vlc_offsets(const VlcPic* __restrict__ 
 __global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__ slices, const uint32_t* __restrict__ slice_blocks, int n_slices,
                                                     const VlcPic* __restrict__ pics, VlcGeom G)
 {
-    const int j = blockIdx.x * 4 + (int)(threadIdx.x >> 6);          // one wave per slice
+    __shared__ uint32_t s_from[4][65], s_at[4][64];                  // per wave: where the round's blocks start in the strip, where they go
+    const int wv = (int)(threadIdx.x >> 6);
+    const int j = blockIdx.x * 4 + wv;                               // one wave per slice
     const int lane = threadIdx.x & 63;
     if (j >= n_slices) return;
     const VlcSlice S = slices[j];
@@ -562,6 +564,7 @@ __global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__
             if (lane >= d) incl += up;
         }
         const uint32_t from = carry + incl - k;
+        const uint32_t round_begin = carry;
         carry += (uint32_t)__shfl((int)incl, 63, 64);
         // Neighbouring lanes often hold the two blocks of one macroblock that lie in the same group (Y0 Y1, Y2 Y3):
         // such a pair takes ONE atomic add -- the launch is bound by their rate.  A lane follows its left neighbour
@@ -576,8 +579,28 @@ __global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__
         if (ok && !follows) at = grp_off[gid] + __hip_atomic_fetch_add(cursor + gid, followed ? k + k_r : k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const uint32_t at_l = (uint32_t)__shfl_up((int)at, 1, 64);
         if (follows) at = at_l + k_l;
-        if (ok && at + k <= P.entries_cap)
-            for (uint32_t i = 0; i < k; i++) entries[at + i] = ent[from + i];
+        // The entries of the round's blocks lie one behind the other in the strip: the wave copies them 64 at a time,
+        // contiguous reads, each lane finding the block its entry belongs to by a binary search over the blocks' start
+        // offsets (in LDS).  A lane copying its own block entry by entry issued as many instructions as the longest
+        // block of the wave is long, each with 64 addresses 4 bytes wide all over memory.
+        s_from[wv][lane] = from;
+        s_at[wv][lane] = ok && at + k <= P.entries_cap ? at : 0xffffffffu;
+        if (lane == 63) s_from[wv][64] = carry;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        const uint32_t round_end = min(carry, S.ent_cap);
+        for (uint32_t e = round_begin + (uint32_t)lane; e < round_end; e += 64u) {
+            uint32_t lo = 0;
+#pragma unroll
+            for (uint32_t step = 32; step != 0; step >>= 1)
+                if (s_from[wv][lo + step] <= e) lo += step;
+            const uint32_t dst = s_at[wv][lo];
+            if (dst != 0xffffffffu) entries[dst + (e - s_from[wv][lo])] = ent[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
 }
 
