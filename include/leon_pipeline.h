@@ -33,7 +33,7 @@ typedef struct leon_pipeline_config {
     int32_t device_id;
     int32_t parser_threads;     /* K; <= 0: one per hardware thread, at most 16 */
     int32_t gops_per_window;    /* W: independent GOPs decoded together = pictures per launch and type; <= 0: 32 */
-    int32_t windows_in_flight;  /* RGBA / staging rings; <= 0: 2 */
+    int32_t windows_in_flight;  /* RGBA / staging rings; <= 0: 2 (3 with gpu_parser) */
     int32_t max_gop_pictures;   /* frames reserved per GOP in a window; <= 0: 16 */
     int32_t loop;               /* benchmarking: decode the stream this many times over (GOP ids keep counting); <= 0: once */
     /* Frame-parallel GOP shards across the GPUs of a node: this pipeline decodes the key-map GOPs
@@ -82,7 +82,7 @@ typedef struct leon_pipeline_stats {
     double   seconds;           /* first parser start -> last window completed (so far) */
     double   parse_seconds_sum; /* summed over the parser threads */
     double   upload_bytes;      /* what crossed PCIe */
-    uint64_t entries;           /* non-zero coefficients decoded */
+    uint64_t entries;           /* non-zero coefficients decoded (host front end; 0 with gpu_parser: they stay on the device) */
 } leon_pipeline_stats;
 
 /* Copies nothing: `stream` must stay valid until leon_pipeline_destroy.  Starts decoding at once. */

@@ -763,7 +763,7 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
     p->total_gops = (uint64_t)p->mine.size() * (uint64_t)loops;
     p->W = cfg->gops_per_window > 0 ? cfg->gops_per_window : 32;
     if ((uint64_t)p->W > p->total_gops) p->W = (int)p->total_gops;
-    p->R = cfg->windows_in_flight > 0 ? cfg->windows_in_flight : 2;
+    p->R = cfg->windows_in_flight > 0 ? cfg->windows_in_flight : (cfg->gpu_parser ? 3 : 2);      // GPU parser: one window being parsed beside one reconstructed and one read
     p->max_pics = cfg->max_gop_pictures > 0 ? cfg->max_gop_pictures : 16;
     int k = cfg->parser_threads;
     if (k <= 0) { k = (int)std::thread::hardware_concurrency(); if (k < 1) k = 1; if (k > 16) k = 16; }
