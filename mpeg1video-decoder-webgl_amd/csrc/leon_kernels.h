@@ -87,14 +87,23 @@ static constexpr int kWavesPerWG = 4;
 // hipGetLastError -- what a 512-thread block-size sweep of the RGBA kernels ran into in round 1).
 static constexpr int kReconMaxThreads = 256;
 static constexpr int kRgbaBlock = 256;
-static constexpr int kLdsCoef = 1024;            // 8 rows x 128 B of int16
-static constexpr int kLdsHandoffPitch = 288;     // 8 rows x 32 B + 32 B skew per block (bank spread)
-static constexpr int kLdsHandoff = 8 * kLdsHandoffPitch;
-static constexpr int kLdsPerWave = kLdsCoef + kLdsHandoff;
-// fused display conversion: the Cb and Cr samples of the task's 8 macroblocks (8 rows x 64 bytes each)
-// wait in LDS for the luma parts of the same task
+// A wave's LDS strip.  The tile holds BOTH block groups of a task, [half][row][block][column] int16, and is
+// worked on in place: coefficients -> (column pass) the int16 hand-off values w -> (row pass reads them).
+static constexpr int kLdsHalf = 1024;            // 8 rows x 128 B of int16: one block group
+static constexpr int kLdsTile = 2 * kLdsHalf;
+static constexpr int kLdsQtab = 256;             // the first 64 dwords of Tables: both matrices and the premultiplier (192 B)
+static constexpr int kLdsSlots = 128;            // column pass: the ids of the live columns, one byte each
+static constexpr int kOffQtab = kLdsTile;
+static constexpr int kOffSlots = kLdsTile + kLdsQtab;
+static constexpr int kLdsPerWave = kOffSlots + kLdsSlots;
+// fused display conversion: the Y rows of a half change lanes through a 512-byte park (it shares its place with the
+// column ids, which are dead by then), and the Cb and Cr samples of the task's 8 macroblocks (8 rows x 64 bytes
+// each) wait in a stash for the luma parts of the same task
+static constexpr int kLdsYpark = 512;
+static constexpr int kOffYpark = kOffSlots;
+static constexpr int kOffStash = kOffYpark + kLdsYpark;
 static constexpr int kLdsStash = 2 * 512;
-static constexpr int kLdsPerWaveDisplay = kLdsPerWave + kLdsStash;
+static constexpr int kLdsPerWaveDisplay = kOffStash + kLdsStash;      // 3840: 4 waves + the tables = 20 KB, 8 workgroups per CU
 static constexpr int kLdsLut = 1280 * 4;         // display kernels: Tables::rgba_lut, one copy per workgroup, in front of the waves' strips
 static constexpr int kLutShift = 21;             // = LEON_RGBA_LUT_SHIFT (static_assert in leon_hip.cpp)
 static constexpr int kLdsPerWaveDisplayAlpha = kLdsPerWaveDisplay + 1024;   // yuva: + the parked A samples of a luma part
@@ -621,36 +630,32 @@ __device__ __forceinline__ void display_half(const PicDesc& pd, const Geom& G, c
 // the same code path as luma with its own coefficient plane, the plane behind Cr in every slot, and the
 // alpha groups of the sparse lists.
 template <int TYPE, bool CHROMA, bool SPARSE, bool DISPLAY, int AMODE = 0>
-__device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, const Tables* __restrict__ Tg,
-                                           int Rt, int g, char* lds, int lane, Display dsp, bool alpha = false)
+__device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int Rt, int g, char* lds, int lane, Display dsp, bool alpha = false)
 {
     const int W = CHROMA ? G.cw >> 1 : G.cw;
     const int H = CHROMA ? G.ch >> 1 : G.ch;
     const int bw = W >> 3;
     const uint32_t ysz = (uint32_t)G.cw * (uint32_t)G.ch;
     const uint32_t a_off = !CHROMA && alpha ? ysz + (ysz >> 1) : 0u;       // byte offset of the A plane in a slot
-    const LEON_GLOBAL Tables* T = gptr(Tg);
     const int hi3 = lane >> 3, lo3 = lane & 7;
 
     // ---- shared prologue ----------------------------------------------------------------
     const int Qld = g * 8 + lo3;                      // stage-1 role: lane (r = hi3, b = lo3)
     const bool ld_ok = Qld < bw;
-    // afterwards: lane (c = hi3, b = lo3) in the column pass and (n = hi3, b = lo3) in the row
-    // pass: the 8 lanes of an aligned group hold the 8 blocks of ONE sample row, so the
-    // reference fetches and the stores of a group are contiguous along a picture row and the
-    // texture addresser merges them into 64-byte accesses (with rows across adjacent lanes every
-    // lane was its own L1 access, and the vector L1 -- one access per clock -- was the limiter)
+    // afterwards: lane (n = hi3, b = lo3) in the row pass and behind it: the 8 lanes of an aligned
+    // group hold the 8 blocks of ONE sample row, so the reference fetches and the stores of a group are
+    // contiguous along a picture row and the texture addresser merges them into 64-byte accesses (with
+    // rows across adjacent lanes every lane was its own L1 access, and the vector L1 -- one access per
+    // clock -- was the limiter)
     const int b = lo3;
     const int Qb = g * 8 + b;
     const bool valid = Qb < bw;
     const int Qs = valid ? Qb : bw - 1;
-    const int c = hi3;
-    // everything that does not depend on the macroblock maps is requested first: the first
-    // coefficient rows and this lane's column of both quantiser matrices and of the premultiplier
-    // (the product quantiser_scale * matrix entry is formed in registers once the maps arrived;
-    // a table indexed by the scale would put a second dependent memory round trip here)
+    // everything that does not depend on the macroblock maps is requested first: the coefficient rows of
+    // BOTH halves (dense boundary: straight into the tile) or the first entries of both runs (sparse)
     const int R0 = CHROMA ? Rt : 2 * Rt;
     const uint32_t coef_voff = (2u * ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)(8 * Qld))) | (ld_ok ? 0u : kOobBit);
+    const uint32_t half_step = CHROMA ? 0u : 8u * (uint32_t)W;   // luma: next block row; chroma: next plane
     // sparse boundary: the two groups of the task are two runs of entries[]; the first 64
     // entries of each are requested here (one dword per lane), longer runs loop in stage 1
     uint32_t ent_first[2] = {0u, 0u}, ent_start[2] = {0u, 0u}, ent_count[2] = {0u, 0u};
@@ -672,10 +677,12 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
                 ent_rs, (int)(((s0 + (uint32_t)lane) * 4u) | ((uint32_t)lane < ent_count[h] ? 0u : kOobBit)), 0, kAuxStreamOnce);
         }
     } else {
+        // the previous task of this wave may still be reading the tile
+        wait_lds_all();
+        __builtin_amdgcn_wave_barrier();
         coef_rows_to_lds(pd.coef[CHROMA ? 1 : (alpha ? 3 : 0)], lds, coef_voff, 0u);
+        coef_rows_to_lds(pd.coef[CHROMA ? 2 : (alpha ? 3 : 0)], lds + kLdsHalf, coef_voff, 2u * half_step);
     }
-    const v2u mI = ldg<v2u>(T, (uint32_t)c * 8u), mN = ldg<v2u>(T, 64u + (uint32_t)c * 8u);
-    const v2u pm8 = ldg<v2u>(T, 128u + (uint32_t)c * 8u);
     const uint32_t mb = (uint32_t)(CHROMA ? Rt * G.mbw + Qs : Rt * G.mbw + (Qs >> 1));
     const int q = ldg<uint8_t>(gptr(pd.qscale), mb) & 31;
     const bool ia = ldg<uint8_t>(gptr(pd.intra), mb) != 0;   // I pictures honour the map too (COL_3)
@@ -719,33 +726,20 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
     const bool useA = usef && !nopred, useB = useb && !nopred;
     inA = inA || !useA;
     inB = inB || !useB;
-    const v2u msel = ia ? mI : mN;
-    uint32_t qv = (uint32_t)q;
-    int nim = ia ? 0 : -1;
-    asm("" : "+v"(nim));                              // keep it a mask (v_and), not a select
-    // the clamp bounds live in registers for the whole task (v_med3 takes no literals on gfx950, and
-    // the compiler would otherwise re-materialise them in front of every use): one scalar, one vector
-    // -- a VOP3 instruction may read one scalar register
-    int lo2048 = -2048, hi2047 = 2047;
-    asm("" : "+s"(lo2048), "+v"(hi2047));
-    const bool dc_lane = c == 0 && ia;
-    char* const lds_wr = lds + hi3 * 128 + lo3 * 16;
-    const char* const lds_col = lds + b * 16 + c * 2;
-    int* const hp = reinterpret_cast<int*>(lds + kLdsCoef + b * kLdsHandoffPitch + c * 4);
-    const v4i* const rp = reinterpret_cast<const v4i*>(lds + kLdsCoef + b * kLdsHandoffPitch + hi3 * 32);
+    // quantiser scale and intra flag of this lane's block, for the lanes of the column pass to fetch (ds_bpermute)
+    const int qia = q | (ia ? 256 : 0);
 
     // per-lane offsets of the task's first half; the second half differs by a scalar
     const uint32_t out_voff = ((uint32_t)__mul24(8 * R0 + hi3, W) + (uint32_t)x0) | (valid ? 0u : kOobBit);
-    const uint32_t half_step = CHROMA ? 0u : 8u * (uint32_t)W;   // luma: next block row; chroma: next plane
     RefRows rfh[2], rbh[2];
     // B pictures: a wave whose macroblocks all predict from one side only (the leading pictures of
     // a closed GOP, runs of forward- or backward-only macroblocks) neither fetches nor interpolates
     // the other reference.  Wave-uniform, so it costs two scalar tests.
     const bool any_f = TYPE != 3 || __builtin_amdgcn_ballot_w64(useA) != 0;
     const bool any_b = TYPE == 3 && __builtin_amdgcn_ballot_w64(useB) != 0;
+    // the coefficient rows (requested before the maps the reference fetches wait for anyway) have landed
+    if constexpr (!SPARSE) wait_vmem_all();
     if (TYPE != 1) {
-        // the first half's coefficient rows (requested before the maps these fetches wait for anyway)
-        if constexpr (!SPARSE) wait_vmem_all();
 #pragma unroll
         for (int h = 0; h < 2; h++) {
             const int Rh = CHROMA ? Rt : 2 * Rt + h;
@@ -754,114 +748,155 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             if (TYPE == 3 && any_b) rbh[h] = fetch_rows(gptr(pd.ref_bwd) + po, W, H, 8 * Rh + hi3, pxB, ayB, ohB, ovB, inB, hi3 == 7, useB);
         }
     }
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const uint32_t plane_off = CHROMA ? (half == 0 ? ysz : ysz + (ysz >> 2)) : a_off;
 
-        RefRows rf = rfh[half], rb = rbh[half];
-
-        // ---- stage 1: the LDS tile [r][b][c] -----------------------------------------------------
-        // dense: this half's coefficient rows were requested half a task ago (coef_rows_to_lds) and have landed
-        // (waited for in front of the reference fetches / the previous half's stores); sparse: clear the tile
-        if constexpr (SPARSE) {
-            *reinterpret_cast<v4i*>(lds_wr) = v4i{0, 0, 0, 0};
-        } else if (TYPE == 1 && half == 0) {
-            wait_vmem_all();                                  // I pictures: no reference fetch in front of which to wait
-        }
+    // ---- stage 1: the tile [half][r][b][c] ---------------------------------------------------------
+    // dense: the rows are there (LDS-direct loads, waited for above); sparse: clear the tile and scatter both runs
+    if constexpr (SPARSE) {
+        *reinterpret_cast<v4i*>(lds + lane * 16) = v4i{0, 0, 0, 0};
+        *reinterpret_cast<v4i*>(lds + kLdsHalf + lane * 16) = v4i{0, 0, 0, 0};
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if constexpr (SPARSE) {
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
             // scatter the group's entries into the cleared tile; the offset is masked to the tile
-            uint32_t e = ent_first[half];
-            if (e != 0u) *reinterpret_cast<short*>(lds + ((e >> 16) & 1022u)) = (short)e;
+            uint32_t e = ent_first[h];
+            if (e != 0u) *reinterpret_cast<short*>(lds + h * kLdsHalf + ((e >> 16) & 1022u)) = (short)e;
 #pragma unroll 1
-            for (uint32_t k = 64u; k < ent_count[half]; k += 64u) {     // wave-uniform, rare
+            for (uint32_t k = 64u; k < ent_count[h]; k += 64u) {     // wave-uniform, rare
                 const uint32_t idx = k + (uint32_t)lane;
                 e = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
-                    ent_rs, (int)(((ent_start[half] + idx) * 4u) | (idx < ent_count[half] ? 0u : kOobBit)), 0, kAuxStreamOnce);
-                if (e != 0u) *reinterpret_cast<short*>(lds + ((e >> 16) & 1022u)) = (short)e;
+                    ent_rs, (int)(((ent_start[h] + idx) * 4u) | (idx < ent_count[h] ? 0u : kOobBit)), 0, kAuxStreamOnce);
+                if (e != 0u) *reinterpret_cast<short*>(lds + h * kLdsHalf + ((e >> 16) & 1022u)) = (short)e;
             }
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-        int t[8];
+    // ---- stage 2: column pass over the LIVE columns of both halves ----------------------------------
+    // A column (half, block, c) without a coefficient gives eight zeros, and zeros are what it holds already.
+    // Quantised video leaves few columns alive (one in ten in P and B pictures, a third in I pictures), so
+    // the lanes first find the live ones -- lane (c = hi3, b = lo3) looks at its own column of each half --
+    // and the wave then runs the pass on them alone, usually in one go for both halves instead of one go
+    // per half with most lanes computing zeros.  The results replace the coefficients in place.
+    uint64_t live[2];
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const char* cp = lds + h * kLdsHalf + lo3 * 16 + hi3 * 2;
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= *reinterpret_cast<const uint16_t*>(cp + i * 128);
+        live[h] = lanes_nonzero((int)o);
+        // the live lanes queue up: position = live lanes below (of half 0: all of them come first)
+        const uint32_t below = h == 0 ? 0u : (uint32_t)__builtin_popcountll(live[0]);
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(live[h] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live[h], below));
+        if (o != 0u) *reinterpret_cast<uint8_t*>(lds + kOffSlots + pos) = (uint8_t)(lane + 64 * h);
+    }
+    const uint32_t n_cols = (uint32_t)__builtin_popcountll(live[0]) + (uint32_t)__builtin_popcountll(live[1]);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    // the clamp bounds live in registers (v_med3 takes no literals on gfx950, and the compiler would
+    // otherwise re-materialise them in front of every use): one scalar, one vector -- a VOP3
+    // instruction may read one scalar register
+    int lo2048 = -2048, hi2047 = 2047;
+    asm("" : "+s"(lo2048), "+v"(hi2047));
+#pragma unroll 1
+    for (uint32_t base = 0; base < n_cols; base += 64u) {             // wave-uniform: once, twice for busy I pictures
+        const uint32_t k = base + (uint32_t)lane;
+        const bool act = k < n_cols;
+        uint32_t id = *reinterpret_cast<const uint8_t*>(lds + kOffSlots + k);        // k <= 127
+        id = act ? id : 0u;                               // idle lanes redo column 0 and write nothing
+        // id = half * 64 + c * 8 + b
+        char* const colp = lds + ((id & 0x47u) << 4) + ((id >> 2) & 14u);
         int X[8];
 #pragma unroll
-        for (int i = 0; i < 8; i++) X[i] = *reinterpret_cast<const short*>(lds_col + i * 128);
-        if constexpr (!SPARSE) {
-            if (half == 0) {
-                // the tile is in registers: the next half's rows may land in it (waited for in front of this half's stores)
-                wait_lds_all();
-                __builtin_amdgcn_wave_barrier();
-                coef_rows_to_lds(pd.coef[CHROMA ? 2 : (alpha ? 3 : 0)], lds, coef_voff, 2u * half_step);
-            }
-        }
+        for (int i = 0; i < 8; i++) X[i] = *reinterpret_cast<const short*>(colp + i * 128);
+        const int bq = __builtin_amdgcn_ds_bpermute((int)((id & 7u) << 2), qia);      // lane b holds block b's macroblock
+        const bool bia = bq >= 256;
+        const uint32_t qv = (uint32_t)bq & 31u;
+        const char* const qt = lds + kOffQtab + (id & 56u);                          // column c of the tables
+        const v2u msel = *reinterpret_cast<const v2u*>(qt + (bia ? 0 : 64));
+        const v2u pm8 = *reinterpret_cast<const v2u*>(qt + 128);
+        int nim = bia ? 0 : -1;
+        asm("" : "+v"(nim));                              // keep it a mask (v_and), not a select
+        const bool dc_lane = bia && (id & 56u) == 0u;
         uint64_t nz[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) nz[i] = lanes_nonzero(X[i]);
-        uint64_t colbits = (nz[0] | nz[1]) | (nz[2] | nz[3]) | (nz[4] | nz[5]) | (nz[6] | nz[7]);
+        const int dc = X[0];
+        int rows_live = 1;                                // wave-uniform: 1 + highest row with a non-zero
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            // a row whose coefficients are zero in every column of the pass costs its compare and a scalar
+            // branch; in a live row every lane runs the branch-free form (zeros stay zero)
+            if (nz[i] != 0) {
+                rows_live = i + 1;
+                int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
+                const int qO = (int)__umul24(qv, ((i < 4 ? msel.x : msel.y) >> (8 * (i & 3))) & 255u);   // quantiser_scale * Q[i][c] < 2^13
+                X[i] = dequant_any(X[i], qO, P, nim, lo2048, hi2047);
+            }
+        }
+        if (dc_lane) X[0] = dc * 256;                     // COL_4 / COL_INT_31
+        const ColOut co = butterfly8_col(X, rows_live);
+        // floor( float(v) * _y ): the int16 the reference hands from pass 1 to pass 2
+        const v2f k04 = {0.4f, 0.4f};
+        const v2f s07 = co.p07 * k04, s16 = co.p16 * k04, s52 = co.p52 * k04, s43 = co.p43 * k04;
+        float wf[8] = {floorf(s07.x), floorf(s16.x), floorf(s52.y), floorf(s43.y),
+                       floorf(s43.x), floorf(s52.x), floorf(s16.y), floorf(s07.y)};
+        const float mx = fmaxf(fmaxf(fmaxf(fabsf(wf[0]), fabsf(wf[1])), fmaxf(fabsf(wf[2]), fabsf(wf[3]))),
+                               fmaxf(fmaxf(fabsf(wf[4]), fabsf(wf[5])), fmaxf(fabsf(wf[6]), fabsf(wf[7]))));
+        int wi[8];
+#pragma unroll
+        for (int n = 0; n < 8; n++) wi[n] = (int)wf[n];
+        if (mx > 32767.0f) {                              // outside any real stream: int16 wrap / saturation
+#pragma unroll
+            for (int n = 0; n < 8; n++) wi[n] = handoff16(wi[n]);
+        }
+        if (act) {
+#pragma unroll
+            for (int n = 0; n < 8; n++) *reinterpret_cast<short*>(colp + n * 128) = (short)wi[n];
+        }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const uint32_t plane_off = CHROMA ? (half == 0 ? ysz : ysz + (ysz >> 2)) : a_off;
+        RefRows rf = rfh[half], rb = rbh[half];
+        int t[8];
+        const uint64_t colbits = live[half];
         if (colbits == 0) {
             // no coefficient in any of the 8 blocks: residual 0 = (0 + 128) / 256
 #pragma unroll
             for (int m = 0; m < 8; m++) t[m] = 128;
         } else {
-            // which coefficient columns are live anywhere in the wave: lane (c,b) -> byte c of the mask
-            const int cols_live = 8 - (__builtin_clzll(colbits | 1ull) >> 3);
-            // ---- stage 2: column pass ------------------------------------------------------
-            const int dc = X[0];
-            asm volatile("" : "+v"(qv));                  // do not share the products between the halves
-            int rows_live = 1;                            // wave-uniform: 1 + highest row with a non-zero
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                // a row whose 64 coefficients are all zero costs its compare and a scalar branch;
-                // in a live row every lane runs the branch-free form (zeros stay zero)
-                if (nz[i] != 0) {
-                    rows_live = i + 1;
-                    int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
-                    // quantiser_scale * Q[i][c] (< 2^13) is formed where it is used: eight products kept
-                    // across both halves would cost the B path a wave of occupancy
-                    const int qO = (int)__umul24(qv, ((i < 4 ? msel.x : msel.y) >> (8 * (i & 3))) & 255u);
-                    X[i] = dequant_any(X[i], qO, P, nim, lo2048, hi2047);
-                }
-            }
-            if (dc_lane) X[0] = dc * 256;                 // COL_4 / COL_INT_31
-            const ColOut co = butterfly8_col(X, rows_live);
-            // floor( float(v) * _y ), then int( w / _y ) == trunc(5w/2) == trunc(w * 2.5f)
-            const v2f k04 = {0.4f, 0.4f}, k25 = {2.5f, 2.5f};
-            const v2f s07 = co.p07 * k04, s16 = co.p16 * k04, s52 = co.p52 * k04, s43 = co.p43 * k04;
-            float wf[8] = {floorf(s07.x), floorf(s16.x), floorf(s52.y), floorf(s43.y),
-                           floorf(s43.x), floorf(s52.x), floorf(s16.y), floorf(s07.y)};
-            const float mx = fmaxf(fmaxf(fmaxf(fabsf(wf[0]), fabsf(wf[1])), fmaxf(fabsf(wf[2]), fabsf(wf[3]))),
-                                   fmaxf(fmaxf(fabsf(wf[4]), fabsf(wf[5])), fmaxf(fabsf(wf[6]), fabsf(wf[7]))));
-            int Xo[8];
-            {
-                const v2f a = v2f{wf[0], wf[1]} * k25, b = v2f{wf[2], wf[3]} * k25;
-                const v2f c2 = v2f{wf[4], wf[5]} * k25, d = v2f{wf[6], wf[7]} * k25;
-                Xo[0] = (int)a.x; Xo[1] = (int)a.y; Xo[2] = (int)b.x; Xo[3] = (int)b.y;      // exact products, cvt truncates
-                Xo[4] = (int)c2.x; Xo[5] = (int)c2.y; Xo[6] = (int)d.x; Xo[7] = (int)d.y;
-            }
-            if (mx > 32767.0f) {                          // outside any real stream: int16 wrap / saturation
-#pragma unroll
-                for (int n = 0; n < 8; n++) {
-                    int w = handoff16((int)wf[n]);
-                    Xo[n] = (5 * w + (int)((unsigned)w >> 31)) >> 1;
-                }
-            }
-#pragma unroll
-            for (int n = 0; n < 8; n++) hp[n * 8] = Xo[n];
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-
             // ---- stage 3: row pass ---------------------------------------------------------
-            // columns that were all zero in every block give zero inputs here (wave-uniform)
-            v4i w0 = rp[0], w1 = {0, 0, 0, 0};
-            if (cols_live > 4) w1 = rp[1];
-            int Y[8] = {w0.x + 128, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};   // "+128" of (t+128)/256
-            butterfly8_n(Y, cols_live, t);
+            // lane (n = hi3, b = lo3): row n of block b, eight int16 w; int( w / _y ) == trunc(5w/2) == trunc(w * 2.5f)
+            // (exact products, the conversion truncates).  Columns that are dead in every block of the half give
+            // zero inputs (wave-uniform): lane (c, b) of the liveness mask -> byte c
+            const int cols_live = 8 - (__builtin_clzll(colbits | 1ull) >> 3);
+            const v4u wv = *reinterpret_cast<const v4u*>(lds + half * kLdsHalf + hi3 * 128 + lo3 * 16);
+            const v2f k25 = {2.5f, 2.5f};
+            const v2f a = v2f{(float)(short)(wv.x & 0xffffu), (float)((int)wv.x >> 16)} * k25;
+            const int Y0 = (int)a.x + 128, Y1 = (int)a.y;                           // "+128" of (t+128)/256
+            if (cols_live <= 2) {
+                butterfly8_lo2(Y0, Y1, t);
+            } else {
+                const v2f bb = v2f{(float)(short)(wv.y & 0xffffu), (float)((int)wv.y >> 16)} * k25;
+                if (cols_live <= 4) {
+                    butterfly8_lo4(Y0, Y1, (int)bb.x, (int)bb.y, t);
+                } else {
+                    const v2f cc = v2f{(float)(short)(wv.z & 0xffffu), (float)((int)wv.z >> 16)} * k25;
+                    const v2f dd = v2f{(float)(short)(wv.w & 0xffffu), (float)((int)wv.w >> 16)} * k25;
+                    const int Y[8] = {Y0, Y1, (int)bb.x, (int)bb.y, (int)cc.x, (int)cc.y, (int)dd.x, (int)dd.y};
+                    butterfly8(Y, t);
+                }
+            }
             // t/256 truncating == arithmetic shift after adding 255 to negative values.  Without a
             // prediction (I pictures) the difference between truncation and floor is invisible:
             // it only exists for negative t, which the final clamp turns into 0 either way.
@@ -900,9 +935,6 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
             t[6] += pred_x256<2>(pred.y);
             t[7] += pred_x256<3>(pred.y);
         }
-        // everything this wave has requested is here by now -- the next half's coefficient rows in particular, so
-        // that no later wait has to count this half's stores
-        if constexpr (!SPARSE) wait_vmem_all();
         v2u o;
         o.x = sat_pk2(t[0], t[1], 8) | (sat_pk2(t[2], t[3], 8) << 16);
         o.y = sat_pk2(t[4], t[5], 8) | (sat_pk2(t[6], t[7], 8) << 16);
@@ -920,22 +952,29 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, con
                 // yuva, A part: the samples wait for the Y part of the same macroblocks
                 *reinterpret_cast<v2u*>(dsp.apark + half * 512 + hi3 * 64 + lo3 * 8) = o;
             } else {
-                // converted right away (stage 5): the rows change lanes through the hand-off strip, free since the
-                // row pass read it (the coefficient tile is already receiving the next half's rows)
-                *reinterpret_cast<v2u*>(lds + kLdsCoef + hi3 * 64 + lo3 * 8) = o;
+                // converted right away (stage 5): the rows change lanes through the park
+                *reinterpret_cast<v2u*>(lds + kOffYpark + hi3 * 64 + lo3 * 8) = o;
             }
         }
-        // the next half overwrites the LDS strip: order its writes behind this half's reads
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if constexpr (DISPLAY && !CHROMA && AMODE != 1) {
-            display_half<AMODE>(pd, G, dsp, lds + kLdsCoef, half, Rt, g, hi3, lo3);
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            display_half<AMODE>(pd, G, dsp, lds + kOffYpark, half, Rt, g, hi3, lo3);
+            // the next half parks its rows in the same place
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
     }
+}
+
+// A wave's copy of the quantiser matrices and the premultiplier (the first 64 dwords of Tables; the column pass
+// reads them by the column its lane was handed): one load and one LDS write per lane, once per wave.
+__device__ __forceinline__ void stage_tables(const Tables* __restrict__ Tg, char* lds, int lane)
+{
+    const uint32_t v = reinterpret_cast<const LEON_GLOBAL uint32_t*>(gptr(Tg))[lane];
+    reinterpret_cast<uint32_t*>(lds + kOffQtab)[lane] = v;
 }
 
 // XCD-aware workgroup remap: hardware deals workgroups round-robin over the 8 XCDs;
@@ -949,21 +988,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int n)
 }
 
 template <int TYPE, bool SPARSE>
-__device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G, const Tables* T,
-                                               int t, char* lds, int lane)
+__device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G, int t, char* lds, int lane)
 {
     const Display none{nullptr, 0};
     if (t < G.tasksY) {
         int Rt = div_inv(t, G.inv_gY), g = t - Rt * G.gY;
-        recon_task<TYPE, false, SPARSE, false>(pd, G, T, Rt, g, lds, lane, none);
+        recon_task<TYPE, false, SPARSE, false>(pd, G, Rt, g, lds, lane, none);
     } else if (t < G.tasksY + G.tasksC) {
         t -= G.tasksY;
         int Rt = div_inv(t, G.inv_gC), g = t - Rt * G.gC;
-        recon_task<TYPE, true, SPARSE, false>(pd, G, T, Rt, g, lds, lane, none);
+        recon_task<TYPE, true, SPARSE, false>(pd, G, Rt, g, lds, lane, none);
     } else {                                   // yuva: the A plane, luma-shaped
         t -= G.tasksY + G.tasksC;
         int Rt = div_inv(t, G.inv_gY), g = t - Rt * G.gY;
-        recon_task<TYPE, false, SPARSE, false>(pd, G, T, Rt, g, lds, lane, none, true);
+        recon_task<TYPE, false, SPARSE, false>(pd, G, Rt, g, lds, lane, none, true);
     }
 }
 
@@ -982,7 +1020,8 @@ __global__ __launch_bounds__(kReconMaxThreads) void k_recon(const PicDesc* __res
     const int t = (wg - pic * G.wg_per_pic) * kWavesPerWG + wave;
     if (t >= G.tasks_per_pic) return;
     char* lds = smem + wave * kLdsPerWave;
-    recon_dispatch<TYPE, SPARSE>(descs[pic], G, T, t, lds, lane);
+    stage_tables(T, lds, lane);
+    recon_dispatch<TYPE, SPARSE>(descs[pic], G, t, lds, lane);
 }
 
 // The same reconstruction with the display conversion fused in (see Display above).  One wave = the 8
@@ -1017,26 +1056,27 @@ void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
     char* lds = smem + wave * (ALPHA ? kLdsPerWaveDisplayAlpha : kLdsPerWaveDisplay);
     const PicDesc& pd = descs[live ? pic : 0];
     const int Rt = div_inv(t, G.inv_gC), gc = t - Rt * G.gC;
-    Display dsp{lds + kLdsPerWave, 0, lds + kLdsPerWaveDisplay, reinterpret_cast<const char*>(lut_s)};
-    if (live) recon_task<TYPE, true, SPARSE, true>(pd, G, T, Rt, gc, lds, lane, dsp);
+    Display dsp{lds + kOffStash, 0, lds + kLdsPerWaveDisplay, reinterpret_cast<const char*>(lut_s)};
+    stage_tables(T, lds, lane);
+    if (live) recon_task<TYPE, true, SPARSE, true>(pd, G, Rt, gc, lds, lane, dsp);
     __syncthreads();
     if (!live) return;
     // the two luma parts as two calls, not a loop: the loop form keeps 15 more registers live (B path: 93).
     // yuva: the A part of the same four macroblocks first (AMODE 1), then the Y part that displays them (AMODE 2).
     dsp.side = 0;
     if constexpr (ALPHA) {
-        recon_task<TYPE, false, SPARSE, true, 1>(pd, G, T, Rt, 2 * gc, lds, lane, dsp, true);
-        recon_task<TYPE, false, SPARSE, true, 2>(pd, G, T, Rt, 2 * gc, lds, lane, dsp);
+        recon_task<TYPE, false, SPARSE, true, 1>(pd, G, Rt, 2 * gc, lds, lane, dsp, true);
+        recon_task<TYPE, false, SPARSE, true, 2>(pd, G, Rt, 2 * gc, lds, lane, dsp);
     } else {
-        recon_task<TYPE, false, SPARSE, true>(pd, G, T, Rt, 2 * gc, lds, lane, dsp);
+        recon_task<TYPE, false, SPARSE, true>(pd, G, Rt, 2 * gc, lds, lane, dsp);
     }
     if (2 * gc + 1 < G.gY) {
         dsp.side = 1;
         if constexpr (ALPHA) {
-            recon_task<TYPE, false, SPARSE, true, 1>(pd, G, T, Rt, 2 * gc + 1, lds, lane, dsp, true);
-            recon_task<TYPE, false, SPARSE, true, 2>(pd, G, T, Rt, 2 * gc + 1, lds, lane, dsp);
+            recon_task<TYPE, false, SPARSE, true, 1>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp, true);
+            recon_task<TYPE, false, SPARSE, true, 2>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp);
         } else {
-            recon_task<TYPE, false, SPARSE, true>(pd, G, T, Rt, 2 * gc + 1, lds, lane, dsp);
+            recon_task<TYPE, false, SPARSE, true>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp);
         }
     }
 }

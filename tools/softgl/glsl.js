@@ -246,8 +246,10 @@ class Compiler {
       const f = e.get, ty = e.type;
       return [(L, G) => { L.ret = copyVal(ty, f(L, G)); return RET; }];
     }
+    // a precision qualifier may precede the type of a local declaration [4.5.2]; it changes nothing here
+    while (this.t[this.p].k === 'id' && ['highp', 'mediump', 'lowp'].includes(this.t[this.p].v) && this.t[this.p + 1].k === 'id' && BASIC.has(this.t[this.p + 1].v)) this.p++;
     if (this.isTypeTok() && this.t[this.p + 1].k === 'id') { const ty = this.ident(); return this.parseDeclarators(ty, false, null); }
-    if (this.peek('const')) { this.p++; const ty = this.ident(); return this.parseDeclarators(ty, false, 'const'); }
+    if (this.peek('const')) { this.p++; while (['highp', 'mediump', 'lowp'].includes(this.t[this.p].v)) this.p++; const ty = this.ident(); return this.parseDeclarators(ty, false, 'const'); }
     const e = this.parseExpr();
     this.expect(';');
     return [exprStmt(e)];
