@@ -138,6 +138,15 @@ typedef struct leon_kernel_stats {
     uint64_t macroblocks;     /* sum over launches */
 } leon_kernel_stats;
 
+/* one timed launch (leon_timing_get_launches) */
+typedef struct leon_launch_time {
+    int32_t kind;             /* 0 = reconstruction kernel, 1 = colour conversion */
+    int32_t pic_type;         /* reconstruction launches: LEON_PIC_I / _P / _B; else 0 */
+    double  ms;               /* HIP-event duration */
+    double  algorithmic_bytes;
+    uint64_t macroblocks;
+} leon_launch_time;
+
 int leon_abi_version(void);
 
 /* thread-local text of the last error returned on this thread */
@@ -219,6 +228,9 @@ int leon_set_overlap_convert(leon_decoder* d, int32_t on);
 int leon_timing_enable(leon_decoder* d, int32_t on);
 int leon_timing_reset(leon_decoder* d);
 int leon_timing_get(leon_decoder* d, int32_t kind, leon_kernel_stats* out);
+/* the timed launches one by one, in submission order: up to `cap` records into out[], *n = how many there are
+ * (bench.py: the spread of a launch class, and the one-sided and the mixed B launches apart) */
+int leon_timing_get_launches(leon_decoder* d, leon_launch_time* out, int32_t cap, int32_t* n);
 
 /* measured device copy bandwidth (GB/s) over `bytes` with a streaming float4
  * copy kernel: the "measured HBM roofline" of BASELINE.md section 2 */

@@ -65,7 +65,12 @@ typedef struct leon_pipeline_frame {
 
 /* Called on the pipeline's notify thread once per window, frames in display order (GOP-major).
  * n_frames == 0 with window < 0 signals the end of the stream ('ended', decoders/jsv.js:437);
- * status != 0 an error (leon_pipeline_error() has the text). */
+ * status != 0 an error (leon_pipeline_error() has the text).
+ * Lifetimes: the `frames` ARRAY belongs to the window -- it is valid until the callback returns or the window is
+ * released, whichever comes first (a callback that releases the window must have read frames[] before; copy what is
+ * kept); the device memory `rgba` points to stays valid until leon_pipeline_release_window(window).  A window
+ * delivered with status != 0 (n_frames may be 0) holds its ring entry and staging like any other and must be
+ * released too. */
 typedef void (*leon_pipeline_callback)(void* user, int64_t window, const leon_pipeline_frame* frames, int32_t n_frames, int32_t status);
 
 typedef struct leon_pipeline_info {

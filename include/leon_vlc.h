@@ -81,6 +81,8 @@ typedef struct leon_vlc_picture {
     const int16_t* mv_bwd;        /* B */
     const uint8_t* mb_dir;        /* B */
     uint32_t n_slices;
+    int32_t open_gop;             /* 1: the first picture behind a GOP header whose closed_gop bit is 0 -- B pictures in
+                                     front of the GOP's second anchor may predict from the GOP before it */
 } leon_vlc_picture;
 
 const char* leon_vlc_last_error(void);
@@ -124,6 +126,8 @@ typedef struct leon_vlc_picture_scan {
     const int32_t* slice_code;           /* [n_slices] slice_vertical_position, 1 .. 175 */
     const uint64_t* slice_bit_pos;       /* [n_slices] first bit behind the slice start code */
     uint64_t end_byte;                   /* the first byte behind the picture's last slice (next start code, or the end) */
+    int32_t open_gop;                    /* as in leon_vlc_picture */
+    int32_t reserved;
 } leon_vlc_picture_scan;
 int leon_vlc_scan_picture(leon_vlc_stream* s, leon_vlc_picture_scan* out);
 

@@ -1077,6 +1077,22 @@ int leon_timing_get(leon_decoder* d, int32_t kind, leon_kernel_stats* out)
     return LEON_OK;
 }
 
+int leon_timing_get_launches(leon_decoder* d, leon_launch_time* out, int32_t cap, int32_t* n)
+{
+    if (!d || !n || (cap > 0 && !out)) return fail(LEON_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(d->dev));
+    HIP_TRY(hipStreamSynchronize(d->stream));
+    if (d->conv_stream) HIP_TRY(hipStreamSynchronize(d->conv_stream));
+    *n = (int32_t)d->timed.size();
+    for (size_t i = 0; i < d->timed.size() && (int32_t)i < cap; i++) {
+        const TimedLaunch& t = d->timed[i];
+        float ms = 0;
+        HIP_TRY(hipEventElapsedTime(&ms, t.a, t.b));
+        out[i] = leon_launch_time{t.kind, t.pic_type, (double)ms, t.bytes, t.mbs};
+    }
+    return LEON_OK;
+}
+
 int leon_measure_copy_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, double* gbps)
 {
     if (!d || !gbps || bytes < 4096 || iters < 1) return fail(LEON_ERR_INVALID, "bad argument");

@@ -30,6 +30,7 @@ struct Arena {                   // pinned host buffer + its device twin, one GO
 };
 
 struct GopJob {
+    bool open_gop = false;       // its GOP header says closed_gop = 0
     uint64_t gop = 0;            // running index among the GOPs of this pipeline
     uint64_t key_gop = 0;        // GOP id in the stream (key-map index, counting on across loops)
     Arena* arena = nullptr;
@@ -154,6 +155,26 @@ bool arena_reserve(leon_pipeline* p, Arena* a, size_t host_need, size_t dev_need
 
 inline Arena* a_of(GopJob* job) { return job->arena; }
 
+// The pipeline takes picture size and quantiser matrices from the stream's FIRST sequence header (leon_create and
+// leon_set_quant_matrices at create time; the parsers emit raw levels, the kernels dequantise).  Every key-map entry
+// starts with a sequence header of its own and the reference reloads the matrices at each (decoders/jsv.js:540-558):
+// a shard whose header says something else would decode to wrong pixels with status OK.  Such a stream is refused.
+bool same_sequence(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, uint64_t g)
+{
+    leon_vlc_info v{};
+    leon_vlc_get_info(st, &v);
+    const char* what = nullptr;
+    if (v.coded_width != p->vinfo.coded_width || v.coded_height != p->vinfo.coded_height ||
+        v.frame_width != p->vinfo.frame_width || v.frame_height != p->vinfo.frame_height) what = "picture size";
+    else if (memcmp(v.intra_qm, p->vinfo.intra_qm, 64) != 0) what = "intra quantiser matrix";
+    else if (memcmp(v.non_intra_qm, p->vinfo.non_intra_qm, 64) != 0) what = "non-intra quantiser matrix";
+    if (!what) return true;
+    job->status = LEON_ERR_INVALID;
+    job->err = std::string("GOP shard ") + std::to_string(g) + ": its sequence header changes the " + what +
+               " (the pipeline decodes a stream with the parameters of its first sequence header)";
+    return false;
+}
+
 // gpu_parser: the host reads the picture layer only (leon_vlc_scan_picture) and lays the GOP's arena out for the
 // device kernels of leon_vlc_gpu.h:
 //   [stream bytes, zero padded]                                            uploaded
@@ -172,6 +193,8 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
             job->err = std::string("GOP shard ") + std::to_string(g) + ": " + leon_vlc_last_error();
             return;
         }
+        if (sc.new_sequence && !same_sequence(p, job, st, g)) return;
+        if (sc.open_gop) job->open_gop = true;
         Scan x;
         x.s = sc;
         x.code.assign(sc.slice_code, sc.slice_code + sc.n_slices);
@@ -282,6 +305,10 @@ void parse_gop(leon_pipeline* p, GopJob* job)
         job->err = std::string("GOP shard ") + std::to_string(g) + ": " + leon_vlc_last_error();
         return;
     }
+    if (!same_sequence(p, job, st, g)) {
+        leon_vlc_close(st);
+        return;
+    }
     const size_t mbs = (size_t)p->vinfo.mb_width * p->vinfo.mb_height;
     const size_t mpad = pad256(mbs), vpad = pad256(mbs * 4), gpad = pad256(((size_t)p->vinfo.n_groups + 1) * 4);
     Arena* a = job->arena;
@@ -300,6 +327,8 @@ void parse_gop(leon_pipeline* p, GopJob* job)
             job->err = std::string("GOP shard ") + std::to_string(g) + ": " + leon_vlc_last_error();
             break;
         }
+        if (pic.new_sequence && !same_sequence(p, job, st, g)) break;
+        if (pic.open_gop) job->open_gop = true;
         const size_t epad = pad256((size_t)pic.n_entries * 4 + 4);
         const size_t need = a->used + gpad + epad + 4 * mpad + 2 * vpad;
         if (!arena_reserve(p, a, need, need)) {
@@ -479,7 +508,11 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
                 it.out = (int)(3 * j) + n_anchor % 3;
             } else {
                 if (newer < 0) return fail(LEON_ERR_INVALID, "GOP %llu: a B picture without an anchor (open GOPs cannot be sharded)", (unsigned long long)job->key_gop);
-                // the leading B pictures of a closed GOP predict backward only (both references = the I picture)
+                // the leading B pictures of a CLOSED GOP predict backward only (both references = the I picture); in an
+                // open GOP (closed_gop = 0) they may predict from the GOP before, which a shard does not have
+                if (older < 0 && job->open_gop)
+                    return fail(LEON_ERR_INVALID, "GOP %llu is open (closed_gop = 0) and its leading B pictures may predict from the GOP before it: "
+                                                  "GOP shards must be closed", (unsigned long long)job->key_gop);
                 it.bwd = newer;
                 it.fwd = older >= 0 ? older : newer;
                 lv = std::max(lv_newer, lv_older) + 1;
@@ -492,6 +525,12 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
             if ((size_t)lv >= levels.size()) levels.resize((size_t)lv + 1);
             levels[(size_t)lv].push_back(it);
             if (m.tref < 0 || m.tref >= p->max_pics) return fail(LEON_ERR_INVALID, "temporal reference %d outside the GOP", m.tref);
+        }
+        // two pictures of a GOP with one temporal reference would be rendered into the same frame of the ring
+        std::vector<uint8_t> seen((size_t)p->max_pics, 0);
+        for (const PipePic& m : job->pics) {
+            if (seen[(size_t)m.tref]) return fail(LEON_ERR_INVALID, "GOP %llu: two pictures with temporal reference %d", (unsigned long long)job->key_gop, m.tref);
+            seen[(size_t)m.tref] = 1;
         }
     }
     hipEvent_t copied = get_event(d);

@@ -303,6 +303,7 @@ struct leon_vlc_stream {
     bool raw_es = false;
     std::vector<uint32_t> keymap;              // (byte offset, time code) pairs
     double ts_pending = 0;
+    bool open_gop_pending = false;          // a GOP header with closed_gop = 0 was read; reported with the next picture
     int temporal_reference = 0;
 
     // per-picture state (decoders/jsv.js:583-676)
@@ -741,6 +742,7 @@ void decode_gop_header(leon_vlc_stream* s)           // decoders/jsv.js:471-489
     const int sec = (int)r.get(6), f = (int)r.get(6);
     const double rate = s->info.picture_rate > 0 ? s->info.picture_rate : 25.0;
     s->ts_pending = ((h * 60 + m) * 60 + sec + (f + 1) / rate) * 1000.0;
+    s->open_gop_pending = r.get(1) == 0;                  // closed_gop; broken_link follows
 }
 
 // decoders/jsv.js:583-676 (+ B pictures).  1 = picture decoded, 0 = not a picture we read, <0 error
@@ -790,6 +792,8 @@ int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
         s->ts_pending = 0;
         out->new_sequence = s->new_sequence ? 1 : 0;
         s->new_sequence = false;
+        out->open_gop = s->open_gop_pending ? 1 : 0;
+        s->open_gop_pending = false;
         out->n_groups = s->info.n_groups;
         out->n_slices = (uint32_t)s->jobs.size();
         return 1;
@@ -864,6 +868,8 @@ int decode_picture(leon_vlc_stream* s, leon_vlc_picture* out)
     s->ts_pending = 0;
     out->new_sequence = s->new_sequence ? 1 : 0;
     s->new_sequence = false;
+    out->open_gop = s->open_gop_pending ? 1 : 0;
+    s->open_gop_pending = false;
     out->n_groups = s->info.n_groups;
     out->n_entries = (uint32_t)s->entries.size();
     out->grp_off = s->grp_off.data();
@@ -1128,6 +1134,7 @@ int leon_vlc_scan_picture(leon_vlc_stream* s, leon_vlc_picture_scan* out)
     out->temporal_reference = p.temporal_reference;
     out->ts_ms = p.ts_ms;
     out->new_sequence = p.new_sequence;
+    out->open_gop = p.open_gop;
     out->full_pel_fwd = s->full_pel_fwd; out->fwd_rsize = s->fwd_rsize;
     out->full_pel_bwd = s->full_pel_bwd; out->bwd_rsize = s->bwd_rsize;
     out->n_slices = p.n_slices;

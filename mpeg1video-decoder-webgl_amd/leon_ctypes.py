@@ -26,6 +26,7 @@ SYMBOLS = [
     "leon_submit_sparse", "leon_batch_create_sparse",
     "leon_convert_rgba", "leon_convert_rgba_batch", "leon_read_planes", "leon_write_planes",
     "leon_read_alpha_plane", "leon_write_alpha_plane", "leon_slot_device_ptr", "leon_sync", "leon_set_overlap_convert", "leon_timing_enable", "leon_timing_reset", "leon_timing_get",
+    "leon_timing_get_launches",
     "leon_measure_copy_bandwidth",
 ]
 # include/leon_pipeline.h (same library)
@@ -69,6 +70,16 @@ class SparsePicture(C.Structure):
 class KernelStats(C.Structure):
     _fields_ = [("launches", C.c_uint64), ("total_ms", C.c_double), ("algorithmic_bytes", C.c_double),
                 ("macroblocks", C.c_uint64)]
+
+
+class LaunchTime(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("pic_type", C.c_int32), ("ms", C.c_double), ("algorithmic_bytes", C.c_double),
+                ("macroblocks", C.c_uint64)]
+
+
+def read_frame(frame):
+    """one frame of a window (a dict handed to on_window) as a host array, through the pipeline that delivered it"""
+    return frame["_pipe"].read_frame(frame)
 
 
 class PipelineConfig(C.Structure):
@@ -145,6 +156,7 @@ def load():
     lib.leon_timing_enable.argtypes = [C.c_void_p, C.c_int32]
     lib.leon_timing_reset.argtypes = [C.c_void_p]
     lib.leon_timing_get.argtypes = [C.c_void_p, C.c_int32, C.POINTER(KernelStats)]
+    lib.leon_timing_get_launches.argtypes = [C.c_void_p, C.POINTER(LaunchTime), C.c_int32, C.POINTER(C.c_int32)]
     lib.leon_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double)]
     lib.leon_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.c_void_p, C.c_size_t, PIPELINE_CB, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.leon_pipeline_get_info.argtypes = [C.c_void_p, C.POINTER(PipelineInfo)]
@@ -353,6 +365,15 @@ class Decoder:
         return {"launches": s.launches, "total_ms": s.total_ms, "algorithmic_bytes": s.algorithmic_bytes,
                 "macroblocks": s.macroblocks}
 
+    def timing_launches(self):
+        """the timed launches one by one, in submission order"""
+        n = C.c_int32()
+        _chk(self.lib.leon_timing_get_launches(self.h, None, 0, C.byref(n)))
+        arr = (LaunchTime * max(1, n.value))()
+        _chk(self.lib.leon_timing_get_launches(self.h, arr, n.value, C.byref(n)))
+        return [{"kind": a.kind, "pic_type": a.pic_type, "ms": a.ms, "algorithmic_bytes": a.algorithmic_bytes,
+                 "macroblocks": a.macroblocks} for a in arr[:n.value]]
+
     def measure_copy_bandwidth(self, nbytes=1 << 31, iters=10):
         g = C.c_double()
         _chk(self.lib.leon_measure_copy_bandwidth(self.h, nbytes, iters, C.byref(g)))
@@ -375,27 +396,39 @@ class Pipeline:
         self.ended = False
         self.error = None
 
+        import threading
+        ready = threading.Event()          # set once self.h exists: decoding starts inside leon_pipeline_create
+
+        def _release(window):
+            rc = self.lib.leon_pipeline_release_window(self.h, window)
+            if rc != OK and self.error is None:
+                self.error = LeonError(rc, "leon_pipeline_release_window(%d): %s" % (window, self.lib.leon_last_error().decode()))
+
         def _cb(_user, window, frames, n, status):
             try:
+                ready.wait()
                 if window < 0:
                     self.ended = True
                     return
-                if status != OK:
+                if status != OK:          # a failed window is delivered too and must be given back like any other
                     self.error = status
-                    self.lib.leon_pipeline_release_window(self.h, window)
+                    _release(window)
                     return
                 self.windows += 1
                 self.frames += n
                 keep = None
                 if self._on_window is not None:
+                    # `_pipe`: a callback may read frames through the dicts alone (read_frame(f) below), without the
+                    # variable its caller assigns the pipeline to -- which does not exist yet while the constructor runs
                     fl = [{"gop": int(frames[i].gop), "display_index": frames[i].display_index, "type": frames[i].type,
-                           "ts_ms": frames[i].ts_ms, "rgba": frames[i].rgba, "_i": i, "_frames": frames} for i in range(n)]
+                           "ts_ms": frames[i].ts_ms, "rgba": frames[i].rgba, "_i": i, "_frames": frames, "_pipe": self} for i in range(n)]
                     keep = self._on_window(window, fl)
                 if keep is not False:
-                    self.lib.leon_pipeline_release_window(self.h, window)
+                    _release(window)
             except Exception as e:      # never let an exception cross the C boundary
                 self.error = e
         self._cb = PIPELINE_CB(_cb)
+        self._ready = ready
         cfg = PipelineConfig(device_id, parser_threads, gops_per_window, windows_in_flight, max_gop_pictures, loop,
                              shard_index, shard_count, float(start_seconds), 1 if gpu_parser else 0, 0)
         h = C.c_void_p()
@@ -404,8 +437,10 @@ class Pipeline:
         _chk(rc)
         self.h = h
         info = PipelineInfo()
-        _chk(self.lib.leon_pipeline_get_info(self.h, C.byref(info)))
+        rc = self.lib.leon_pipeline_get_info(self.h, C.byref(info))
         self.info = info
+        ready.set()
+        _chk(rc)
 
     def read_frame(self, frame):
         out = np.empty((self.info.frame_height, self.info.frame_width, 4), dtype=np.uint8)
@@ -427,6 +462,7 @@ class Pipeline:
 
     def close(self):
         if self.h:
+            self._ready.set()
             self.lib.leon_pipeline_destroy(self.h)
             self.h = None
 

@@ -16,7 +16,7 @@ class PictureScan(C.Structure):
     _fields_ = [("type", C.c_int32), ("temporal_reference", C.c_int32), ("ts_ms", C.c_double), ("new_sequence", C.c_int32),
                 ("full_pel_fwd", C.c_int32), ("fwd_rsize", C.c_int32), ("full_pel_bwd", C.c_int32), ("bwd_rsize", C.c_int32),
                 ("n_slices", C.c_uint32), ("slice_code", C.POINTER(C.c_int32)), ("slice_bit_pos", C.POINTER(C.c_uint64)),
-                ("end_byte", C.c_uint64)]
+                ("end_byte", C.c_uint64), ("open_gop", C.c_int32), ("reserved", C.c_int32)]
 
 
 class GpuTables(C.Structure):
@@ -39,7 +39,7 @@ class Picture(C.Structure):
                 ("grp_off", C.POINTER(C.c_uint32)), ("entries", C.POINTER(C.c_uint32)),
                 ("qscale", C.POINTER(C.c_uint8)), ("intra", C.POINTER(C.c_uint8)), ("repadd", C.POINTER(C.c_uint8)),
                 ("mv_fwd", C.POINTER(C.c_int16)), ("mv_bwd", C.POINTER(C.c_int16)), ("mb_dir", C.POINTER(C.c_uint8)),
-                ("n_slices", C.c_uint32)]
+                ("n_slices", C.c_uint32), ("open_gop", C.c_int32)]
 
 
 _lib = None
@@ -118,7 +118,7 @@ class Stream:
         I = self.refresh_info()
         nmb = I.mb_width * I.mb_height
         out = {"type": p.type, "temporal_reference": p.temporal_reference, "ts": p.ts_ms, "new_sequence": bool(p.new_sequence),
-               "n_slices": p.n_slices,
+               "n_slices": p.n_slices, "open_gop": bool(p.open_gop),
                "grp_off": _arr(p.grp_off, p.n_groups + 1, np.uint32), "entries": _arr(p.entries, p.n_entries, np.uint32),
                "qscale": _arr(p.qscale, nmb, np.uint8), "intra": _arr(p.intra, nmb, np.uint8),
                "repadd": _arr(p.repadd, nmb, np.uint8), "mv_fwd": _arr(p.mv_fwd, 2 * nmb, np.int16),

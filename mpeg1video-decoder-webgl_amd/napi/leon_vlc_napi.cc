@@ -101,7 +101,7 @@ napi_value NextPicture(napi_env env, napi_callback_info info)
     const size_t mbs = (size_t)I.mb_width * I.mb_height;
     napi_create_object(env, &o);
     set_num(env, o, "type", p.type); set_num(env, o, "temporalReference", p.temporal_reference);
-    set_num(env, o, "ts", p.ts_ms); set_num(env, o, "newSequence", p.new_sequence);
+    set_num(env, o, "ts", p.ts_ms); set_num(env, o, "newSequence", p.new_sequence); set_num(env, o, "openGop", p.open_gop);
     set_num(env, o, "nSlices", p.n_slices); set_num(env, o, "nEntries", p.n_entries);
     napi_set_named_property(env, o, "grpOff", copy_array(env, napi_uint32_array, p.grp_off, (size_t)p.n_groups + 1, 4));
     napi_set_named_property(env, o, "entries", copy_array(env, napi_uint32_array, p.entries, p.n_entries, 4));

@@ -31,12 +31,14 @@ def oracle_decode_sequence(O, cw, ch, pics, refs, qm=None):
     return out
 
 
-def hip_submit(L, dec, t, keep):
+def hip_submit(L, dec, t, keep, rgba_out=None):
+    """rgba_out (a device pointer): the fused path, k_recon_display -- planes AND the RGBA frame from one launch"""
+    extra = {} if rgba_out is None else dict(rgba_out=rgba_out, no_planes=False)
     p = L.make_picture(t["type"], t["slot"], t["coef_y"], t["coef_cb"], t["coef_cr"], t["qscale"], t["intra"],
                        repadd=t.get("repadd"), mv_fwd=t.get("mv_fwd"), mv_bwd=t.get("mv_bwd"),
                        mb_dir=t.get("mb_dir"),
                        ref_fwd_slot=-1 if t.get("ref_fwd") is None else t["ref_fwd"],
-                       ref_bwd_slot=-1 if t.get("ref_bwd") is None else t["ref_bwd"], keep=keep)
+                       ref_bwd_slot=-1 if t.get("ref_bwd") is None else t["ref_bwd"], keep=keep, **extra)
     dec.submit_picture(p)
 
 
@@ -44,8 +46,9 @@ def planes_flat(y, cb, cr):
     return np.concatenate([y.ravel(), cb.ravel(), cr.ravel()])
 
 
-def hip_submit_sparse(L, dec, t, keep, cw, ch):
+def hip_submit_sparse(L, dec, t, keep, cw, ch, rgba_out=None):
     """The same picture through the sparse boundary (include/leon_vlc.h lists)."""
+    extra = {} if rgba_out is None else dict(rgba_out=rgba_out, no_planes=False)
     import leon_vlc_ctypes as V
     if "grp_off" in t and t.get("entries") is not None:
         grp_off, entries = t["grp_off"], t["entries"]
@@ -55,5 +58,5 @@ def hip_submit_sparse(L, dec, t, keep, cw, ch):
                               repadd=t.get("repadd"), mv_fwd=t.get("mv_fwd"), mv_bwd=t.get("mv_bwd"),
                               mb_dir=t.get("mb_dir"),
                               ref_fwd_slot=-1 if t.get("ref_fwd") is None else t["ref_fwd"],
-                              ref_bwd_slot=-1 if t.get("ref_bwd") is None else t["ref_bwd"], keep=keep)
+                              ref_bwd_slot=-1 if t.get("ref_bwd") is None else t["ref_bwd"], keep=keep, **extra)
     dec.submit_sparse([p], L.MEM_HOST)

@@ -33,6 +33,7 @@ def test_struct_layouts():
     assert C.sizeof(L.Config) == 40 and L.Config.stream.offset == 24 and L.Config.alpha.offset == 32
     assert C.sizeof(L.Picture) == 16 + 9 * 8 + 16 + 8 and L.Picture.coef_y.offset == 16 and L.Picture.rgba_out.offset == 88 and L.Picture.coef_a.offset == 104
     assert C.sizeof(L.KernelStats) == 32
+    assert C.sizeof(L.LaunchTime) == 32 and L.LaunchTime.ms.offset == 8
 
 
 def test_no_cpu_fallback_without_device():

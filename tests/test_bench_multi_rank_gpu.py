@@ -26,3 +26,27 @@ def test_two_ranks_decode_disjoint_gops_with_matching_checksums():
     assert 0.2 < d["efficiency"] < 1.2 and d["single_rank_same_run"]["value"] > 0
     for k in ("metric", "value", "unit", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "roofline"):
         assert k in d
+    # the line says who ran: backend, the world size the process group saw, every rank's device
+    assert d["backend"] == "gloo" and d["world_size_seen"] == 2
+    assert [x["rank"] for x in d["devices"]] == [0, 1] and all(x["name"] and x["pci"] for x in d["devices"])
+    assert d["distinct_devices"] == 1              # the rehearsal: both ranks on device 0 (LEON_BENCH_ONE_DEVICE)
+    # the one-sided and the mixed B launches apart, each with the spread of its launch times
+    pt = d["roofline"]["per_picture_type"]
+    assert {"I", "P", "B", "B_leading", "B_mixed"} <= set(pt)
+    for v in pt.values():
+        assert v["launch_ms"]["min"] <= v["launch_ms"]["median"] <= v["launch_ms"]["max"] and v["launches"] > 0
+    assert pt["B_leading"]["bytes_per_macroblock"] < pt["B_mixed"]["bytes_per_macroblock"]
+    assert pt["B_leading"]["launches"] + pt["B_mixed"]["launches"] == pt["B"]["launches"]
+
+
+def test_ranks_without_distinct_devices_are_refused():
+    """two ranks on a one-GPU box are an error unless the rehearsal knob says so: rank 1 finds no device of its own"""
+    env = dict(os.environ, LEON_BENCH_BACKEND="gloo")
+    env.pop("LEON_BENCH_ONE_DEVICE", None)
+    import torch
+    if torch.cuda.device_count() != 1:
+        pytest.skip("needs a box with exactly one GPU")
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--gops", "2", "--unique", "1", "--steps", "1",
+                          "--warmup", "0", "--no-cpu-baseline", "--no-second-recipe"], env=env, capture_output=True, text=True, timeout=900)
+    assert out.returncode != 0
+    assert not [l for l in out.stdout.splitlines() if l.startswith("{")], "a result line although a rank had no device"

@@ -1,6 +1,9 @@
 """GPU: libleon_hip.so (through the C ABI) against the vectors produced by executing the
 reference's own shader text on tools/softgl (tests/golden/glsl_*.json, see
-tests/test_glsl_golden.py).  Bit-exact, dense and sparse boundary."""
+tests/test_glsl_golden.py).  Bit-exact, dense and sparse boundary, and both launch forms: the plain
+reconstruction kernel (k_recon) and the one with the display conversion fused in (k_recon_display, what
+bench.py and the pipeline run): its planes against the same fixtures, its RGBA frame against the oracle's
+CPU twin of the reference's YCbCrToRGBA applied to the fixture's planes."""
 import os
 
 import numpy as np
@@ -24,12 +27,21 @@ def split(flat, cw, ch):
     return flat[:n].reshape(ch, cw), flat[n:n + n // 4].reshape(ch // 2, cw // 2), flat[n + n // 4:].reshape(ch // 2, cw // 2)
 
 
+def rgba_twin(flat, cw, ch):
+    from oracle import oracle_py as O
+    return O.ycbcr_to_rgba(*O.split_planes(flat, cw, ch), cw, cw, ch, "cpu")
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["k_recon", "k_recon_display"])
 @pytest.mark.parametrize("sparse", [False, True], ids=["dense", "sparse"])
 @pytest.mark.parametrize("case", CASES, ids=lambda c: c["name"])
-def test_hip_equals_reference_shaders(L, case, sparse):
+def test_hip_equals_reference_shaders(L, case, sparse, fused):
+    import torch
     cw, ch = case["coded_w"], case["coded_h"]
     qm = unz(case["quant_matrices"])
     dec = L.Decoder(cw, ch, n_slots=4)
+    frame = torch.zeros((ch, cw, 4), dtype=torch.uint8, device="cuda") if fused else None
+    rgba_out = frame.data_ptr() if fused else None
     try:
         dec.set_quant_matrices(qm[:64], qm[64:])
         keep = []
@@ -42,19 +54,22 @@ def test_hip_equals_reference_shaders(L, case, sparse):
                 # predict from the REFERENCE's previous output, so one differing picture cannot hide the next
                 dec.write_planes(0, *split(prev, cw, ch))
                 t["ref_fwd"] = 0
-            (hip_submit_sparse(L, dec, t, keep, cw, ch) if sparse else hip_submit(L, dec, t, keep))
+            (hip_submit_sparse(L, dec, t, keep, cw, ch, rgba_out) if sparse else hip_submit(L, dec, t, keep, rgba_out))
             got = planes_flat(*dec.read_planes(1))
             ref = np.concatenate([unz(x) for x in p["planes"]])
             bad = np.nonzero(got != ref)[0]
             assert bad.size == 0, "%s picture %d (type %d): %d samples differ, first at %d (got %d want %d)" % (
                 case["name"], i, p["type"], bad.size, bad[0], got[bad[0]], ref[bad[0]])
+            if fused:
+                assert np.array_equal(frame.cpu().numpy(), rgba_twin(ref, cw, ch)), "%s picture %d: RGBA frame" % (case["name"], i)
             prev = ref
     finally:
         dec.close()
 
 
+@pytest.mark.parametrize("fused", [False, True], ids=["k_recon", "k_recon_display"])
 @pytest.mark.parametrize("s", STREAMS, ids=lambda s: s["stream"])
-def test_stream_through_native_front_end_and_hip(L, s):
+def test_stream_through_native_front_end_and_hip(L, s, fused):
     """stream bytes -> libleon_vlc.so -> leon_submit_sparse -> planes == the reference's own
     decode of the same bytes (its parser, its IDCT_GL, its shaders on softgl)."""
     import leon_vlc_ctypes as V
@@ -62,7 +77,9 @@ def test_stream_through_native_front_end_and_hip(L, s):
     st = V.Stream(data)
     cw, ch = s["coded_w"], s["coded_h"]
     qm = unz(s["custom_intra_matrix"])
+    import torch
     dec = L.Decoder(cw, ch, n_slots=4)
+    frame = torch.zeros((ch, cw, 4), dtype=torch.uint8, device="cuda") if fused else None
     try:
         dec.set_quant_matrices(qm[:64], qm[64:])
         keep = []
@@ -75,9 +92,12 @@ def test_stream_through_native_front_end_and_hip(L, s):
             t = dict(p)
             t["slot"] = n & 1
             t["ref_fwd"] = None if p["type"] == 1 else (n & 1) ^ 1
-            hip_submit_sparse(L, dec, t, keep, cw, ch)
-            got = [sha(x) for x in dec.read_planes(n & 1)]
+            hip_submit_sparse(L, dec, t, keep, cw, ch, frame.data_ptr() if fused else None)
+            planes = dec.read_planes(n & 1)
+            got = [sha(x) for x in planes]
             assert got == r["planes_sha256"], "picture %d of %s" % (n, s["stream"])
+            if fused:
+                assert np.array_equal(frame.cpu().numpy(), rgba_twin(planes_flat(*planes), cw, ch)), "picture %d of %s: RGBA frame" % (n, s["stream"])
             n += 1
         assert n == len(s["pictures"])
     finally:

@@ -47,16 +47,21 @@ def test_ibbp_windows_and_loops(L, window, threads, inflight):
 
 
 def test_same_frames_as_the_host_front_end_at_1080p(L):
-    """one 1080p GOP (68 slices per picture): byte for byte the frames of the pipeline that parses on the host"""
-    path = os.path.join(ROOT, "tools", "probe", "stream_1080p_2gop.bin")
-    if not os.path.exists(path):
-        pytest.skip("tools/probe/stream_1080p_2gop.bin is not there (tools/parse_bench.py writes it)")
-    data = open(path, "rb").read()
+    """two 1080p GOPs (68 slices per picture, tools/stream_1080p.py writes the stream when it is not there): byte for
+    byte the frames of the pipeline that parses on the host -- and both equal the oracle run on the host front end's
+    tensors, all 24 pictures"""
+    import stream_1080p
+    data = stream_1080p.load()
     host, _, _ = run_pipeline(L, data, parser_threads=8, gops_per_window=2)
     gpu, _, _ = run_pipeline(L, data, parser_threads=2, gops_per_window=2, gpu_parser=True)
     assert set(host) == set(gpu) and len(gpu) == 24
     for k in host:
         assert np.array_equal(host[k], gpu[k]), k
+    want = oracle_frames(data)
+    assert set(want) == set(gpu)
+    for k in sorted(want):
+        bad = np.argwhere((gpu[k] != want[k]).any(axis=2))
+        assert bad.size == 0, "frame %s: %d pixels differ from the oracle, rows %d..%d" % (k, len(bad), bad[:, 0].min(), bad[:, 0].max())
 
 
 def test_damaged_streams_are_refused(L):
@@ -103,7 +108,7 @@ def test_random_corruption_never_hangs_or_faults(L):
 
         def on_window(window, frames):
             for f in frames:
-                got[(f["gop"], f["display_index"])] = pipe.read_frame(f)
+                got[(f["gop"], f["display_index"])] = L.read_frame(f)
         pipe = L.Pipeline(bytes(bad), gops_per_window=3, parser_threads=1, max_gop_pictures=64, gpu_parser=True, on_window=on_window)
         try:
             try:

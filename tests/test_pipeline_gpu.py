@@ -62,7 +62,7 @@ def run_pipeline(L, data, **kw):
 
     def on_window(window, frames):
         for f in frames:
-            got[(f["gop"], f["display_index"])] = pipe.read_frame(f)
+            got[(f["gop"], f["display_index"])] = L.read_frame(f)       # not `pipe`: unassigned while the constructor runs
             order.append((f["gop"], f["display_index"], f["ts_ms"]))
     pipe = L.Pipeline(data, on_window=on_window, **kw)
     try:
@@ -74,7 +74,8 @@ def run_pipeline(L, data, **kw):
     return got, order, stats
 
 
-def ibbp_stream(cw, ch, gops, seed):
+def ibbp_stream(cw, ch, gops, seed, gop_qm=None):
+    """gop_qm: {GOP number: (intra matrix, non-intra matrix)} for GOPs whose sequence header carries matrices of its own"""
     import jsv_writer as W
     import synth as S
     rng = np.random.default_rng(seed)
@@ -85,7 +86,8 @@ def ibbp_stream(cw, ch, gops, seed):
             t = S.make_picture(rng, cw, ch, ptype, force_dir=2 if (ptype == S.PIC_B and f is None) else None)
             t["display"] = disp
             pics.append(t)
-    return W.write_stream(pics, cw, ch, cw, ch, gop_starts=starts)[0]
+    qm = {starts[g]: m for g, m in (gop_qm or {}).items()}
+    return W.write_stream(pics, cw, ch, cw, ch, gop_starts=starts, gop_qm=qm)[0]
 
 
 @pytest.mark.parametrize("name", ["leon_synth_352x240", "slices5_ip_96x64", "custom_intra_ip_48x32", "tiny_ip_32x32"])
@@ -189,6 +191,30 @@ def test_pipeline_errors(L):
             pipe.wait()
     finally:
         pipe.close()
+
+
+@pytest.mark.parametrize("gpu_parser", [False, True], ids=["host-parser", "gpu-parser"])
+@pytest.mark.parametrize("which", ["intra", "non-intra"])
+def test_a_later_sequence_header_with_other_matrices_is_refused(L, gpu_parser, which):
+    """the pipeline dequantises with the matrices of the stream's first sequence header; every key-map GOP has a
+    sequence header of its own (the reference reloads the matrices at each, decoders/jsv.js:540-558): a GOP whose
+    header carries another matrix ends the run with an error instead of wrong pixels"""
+    other = (np.arange(64, dtype=np.uint8) + 20)
+    other[0] = 8
+    qm = (other, None) if which == "intra" else (None, other)
+    data = ibbp_stream(96, 64, [6, 6, 6], seed=11, gop_qm={1: qm})
+    pipe = L.Pipeline(data, gops_per_window=1, parser_threads=1, max_gop_pictures=64, gpu_parser=gpu_parser)
+    try:
+        with pytest.raises(L.LeonError) as e:
+            pipe.wait()
+        assert "sequence header changes the %s quantiser matrix" % which in str(e.value)
+    finally:
+        pipe.close()
+    # the same matrices in EVERY header are fine
+    same = ibbp_stream(96, 64, [6, 6], seed=11, gop_qm={0: qm, 1: qm})
+    want = oracle_frames(same)
+    got, _, _ = run_pipeline(L, same, parser_threads=2, gops_per_window=2, gpu_parser=gpu_parser, max_gop_pictures=64)
+    assert set(got) == set(want) and all(np.array_equal(got[k], want[k]) for k in want)
 
 
 @pytest.mark.parametrize("gpu_parser", [False, True], ids=["host-parser", "gpu-parser"])

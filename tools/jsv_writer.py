@@ -329,9 +329,11 @@ def write_picture(bw, t, cw, ch, temporal_ref, f_code=(2, 2), full_pel=(0, 0), s
 
 
 def write_stream(pictures, cw, ch, frame_w=None, frame_h=None, rate_idx=3, gop_starts=None,
-                 qm_intra=None, qm_non_intra=None, key_map=True, f_code=(2, 2), slice_mbs=None, alpha=None):
+                 qm_intra=None, qm_non_intra=None, key_map=True, f_code=(2, 2), slice_mbs=None, alpha=None, gop_qm=None):
     """pictures: tensors dicts in CODED order, each with 'display' (temporal reference inside
     its GOP).  gop_starts: indices into `pictures` where a sequence header + GOP header go.
+    gop_qm: {index into `pictures`: (qm_intra, qm_non_intra)} -- matrices of that GOP's own sequence header
+    instead of the stream's (a sequence header may reload them, decoders/jsv.js:540-558).
     Returns bytes."""
     frame_w, frame_h = frame_w or cw, frame_h or ch
     gop_starts = sorted(set(gop_starts or [0]))
@@ -352,7 +354,7 @@ def write_stream(pictures, cw, ch, frame_w=None, frame_h=None, rate_idx=3, gop_s
             body.put(1, 1)
             body.put(1, 10)                                # vbv buffer size: 16 KiB look-ahead
             body.put(0, 1)
-            for qm in (qm_intra, qm_non_intra):
+            for qm in (gop_qm[i] if gop_qm and i in gop_qm else (qm_intra, qm_non_intra)):
                 if qm is None:
                     body.put(0, 1)
                 else:
