@@ -29,12 +29,16 @@ extern "C" {
 
 typedef struct leon_pipeline leon_pipeline;
 
+#define LEON_PIPELINE_PARSER_DEFAULT 0
+#define LEON_PIPELINE_PARSER_GPU 1
+#define LEON_PIPELINE_PARSER_HOST (-1)
+
 typedef struct leon_pipeline_config {
     int32_t device_id;
     int32_t parser_threads;     /* K; <= 0: one per hardware thread, at most 16 */
     int32_t gops_per_window;    /* W: independent GOPs decoded together = pictures per launch and type; <= 0: 32 */
     int32_t windows_in_flight;  /* RGBA / staging rings; <= 0: 2 (3 with gpu_parser) */
-    int32_t max_gop_pictures;   /* frames reserved per GOP in a window; <= 0: 16 */
+    int32_t max_gop_pictures;   /* frames reserved per GOP in a window; <= 0: the longest GOP of the stream (counted at create) */
     int32_t loop;               /* benchmarking: decode the stream this many times over (GOP ids keep counting); <= 0: once */
     /* Frame-parallel GOP shards across the GPUs of a node: this pipeline decodes the key-map GOPs
      * g with g % shard_count == shard_index only -- one process (or pipeline) per GPU, each with its device_id,
@@ -46,10 +50,13 @@ typedef struct leon_pipeline_config {
      * host seeks by destroying it and creating one at the new time, as the reference frees all its output
      * buffers on a seek, jsv.js:1623.) */
     double start_seconds;
-    /* != 0: the slice layer (everything below a slice start code: macroblock headers, vectors, coefficients --
-     * decodeSlice .. decodeBlockGL, decoders/jsv.js:683-1525) is decoded on the GPU, one lane per slice
-     * (csrc/leon_vlc_gpu.h); the parser threads only read the picture layer and upload the stream bytes.  Same
-     * frames; errors of a slice surface when its window completes.  0: on the parser threads (libleon_vlc.so). */
+    /* Where the slice layer is decoded (everything below a slice start code: macroblock headers, vectors, coefficients
+     * -- decodeSlice .. decodeBlockGL, decoders/jsv.js:683-1525):
+     *   LEON_PIPELINE_PARSER_DEFAULT (0) and LEON_PIPELINE_PARSER_GPU (1): on the GPU, one lane per slice
+     *     (csrc/leon_vlc_gpu.h); the parser threads only read the picture layer and upload the stream bytes.  Errors of
+     *     a slice surface when its window completes.  The default since round 3: six times the host front end.
+     *   LEON_PIPELINE_PARSER_HOST (-1): on the parser threads (libleon_vlc.so).
+     * Same frames either way. */
     int32_t gpu_parser;
     int32_t reserved;
 } leon_pipeline_config;

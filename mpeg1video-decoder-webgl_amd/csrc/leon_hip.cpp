@@ -318,7 +318,8 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
         G.wg_per_pic = (G.tasks_per_pic + kWavesPerWG - 1) / kWavesPerWG;
         G.inv_wg_per_pic = G.wg_per_pic == 1 ? 0u : (uint32_t)(((1ull << 32) + G.wg_per_pic - 1) / G.wg_per_pic);
     }
-    long long wgs = (long long)n * G.wg_per_pic;
+    // B launches: the workgroups of two consecutive pictures alternate (pic_of_wg), an odd last picture leaves its partner's idle
+    long long wgs = (long long)(type == LEON_PIC_B && LEON_PAIR_B ? (n + 1) / 2 * 2 : n) * G.wg_per_pic;
     // the kernel divides by multiply-high: exact while n_wg * wg_per_pic < 2^32
     if (wgs > 0x7fffffffLL || wgs * G.wg_per_pic >= (1LL << 32))
         return fail(LEON_ERR_INVALID, "batch of %d pictures is too large for one launch; split it", n);

@@ -38,8 +38,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#ifndef LEON_LATE_FETCH
-#define LEON_LATE_FETCH 1
+#ifndef LEON_PAIR_B
+#define LEON_PAIR_B 1
 #endif
 
 namespace leon {
@@ -135,17 +135,10 @@ __device__ __forceinline__ int mad24k(int a, int k, int c)
     return d;
 }
 
-// {sat_u8(a >> sh), sat_u8(b >> sh)} in the low 16 bits (gfx950 v_ashr_pk_u8_i32).
-// Always through the builtin: hipcc's own pattern match of med3(ashr)|shl onto this
-// instruction (ROCm 7.2) forgets that the instruction leaves the upper 16 destination
-// bits alone, which corrupted bytes 2..3 of the packed result for negative inputs.
-__device__ __forceinline__ uint32_t sat_pk2(int a, int b, uint32_t sh)
-{
-    return (uint32_t)__builtin_amdgcn_ashr_pk_u8_i32(a, b, sh) & 0xffffu;
-}
-
-// {sat_u8(a >> sh), sat_u8(b >> sh), sat_u8(c >> sh), sat_u8(d >> sh)}: two v_ashr_pk_u8_i32, the second one into the
-// high half of the same register (op_sel[3]; each leaves the other half alone)
+// {sat_u8(a >> SH), sat_u8(b >> SH), sat_u8(c >> SH), sat_u8(d >> SH)}: two v_ashr_pk_u8_i32 (gfx950), the second one
+// into the high half of the same register (op_sel[3]; each leaves the other half alone).  Through asm: hipcc's own
+// pattern match of med3(ashr)|shl onto this instruction (ROCm 7.2) forgets that it leaves half of the destination
+// alone, and the builtin does not know the half-selecting form.
 template <int SH>
 __device__ __forceinline__ uint32_t sat_pk4(int a, int b, int c, int d)
 {
@@ -383,6 +376,14 @@ __device__ __forceinline__ int dequant_any(int X, int qO, int pm, int nim, int l
     return __mul24(f, pm);
 }
 
+// (int)floorf(x) in one instruction
+__device__ __forceinline__ int cvt_floor(float x)
+{
+    int d;
+    asm("v_cvt_flr_i32_f32 %0, %1" : "=v"(d) : "v"(x));
+    return d;
+}
+
 // _B()/_E() int16 hand-off incl. UNORM8 saturation of the high byte (mpeg1video.js:18)
 __device__ __forceinline__ int handoff16(int w)
 {
@@ -524,47 +525,6 @@ __device__ __forceinline__ uint32_t pred_x256(uint32_t pred)
     // re-materialise it in a vector register in front of every group of uses.
     uint32_t d;
     asm("v_perm_b32 %0, 0, %1, %2" : "=v"(d) : "v"(pred), "s"(0x0c0c000cu | ((uint32_t)M << 8)));
-    return d;
-}
-
-// ---- int16 pairs (the tile holds them: hand-off values, then residuals) ---------------------------------
-// one 16-bit half of a dword, sign-extended and converted to float: one SDWA instruction
-template <int HI>
-__device__ __forceinline__ float half_to_float(uint32_t v)
-{
-    float f;
-    if constexpr (HI) asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(v));
-    else asm("v_cvt_f32_i32_sdwa %0, sext(%1) dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(f) : "v"(v));
-    return f;
-}
-// {sat_i16(a), sat_i16(b)}
-__device__ __forceinline__ uint32_t pack_sat16(int a, int b)
-{
-    uint32_t d;
-    asm("v_cvt_pk_i16_i32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// bytes 2K and 2K+1 of `pred` as two 16-bit values (selector byte 0x0c = constant 0; it rides in a scalar register)
-template <int K>
-__device__ __forceinline__ uint32_t pred_pair(uint32_t pred)
-{
-    uint32_t d;
-    asm("v_perm_b32 %0, 0, %1, %2" : "=v"(d) : "v"(pred), "s"(K == 0 ? 0x0c010c00u : 0x0c030c02u));
-    return d;
-}
-// two saturating 16-bit additions
-__device__ __forceinline__ uint32_t add_sat16x2(uint32_t a, uint32_t b)
-{
-    uint32_t d;
-    asm("v_pk_add_i16 %0, %1, %2 clamp" : "=v"(d) : "v"(a), "v"(b));
-    return d;
-}
-// {sat_u8 of the two 16-bit halves of lo, then of hi}: v_sat_pk_u8_i16 into the low half, again (SDWA) into the high half
-__device__ __forceinline__ uint32_t sat_u8x4(uint32_t lo, uint32_t hi)
-{
-    uint32_t d;
-    asm("v_sat_pk_u8_i16_e32 %0, %1" : "=v"(d) : "v"(lo));
-    asm("v_sat_pk_u8_i16_sdwa %0, %1 dst_sel:WORD_1 dst_unused:UNUSED_PRESERVE src0_sel:DWORD" : "+v"(d) : "v"(hi));
     return d;
 }
 
@@ -795,15 +755,14 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
     const bool any_b = TYPE == 3 && __builtin_amdgcn_ballot_w64(useB) != 0;
     // the coefficient rows (requested before the maps the reference fetches wait for anyway) have landed
     if constexpr (!SPARSE) wait_vmem_all();
-    auto fetch_half = [&](int h) {
-        const int Rh = CHROMA ? Rt : 2 * Rt + h;
-        const uint32_t po = CHROMA ? (h == 0 ? ysz : ysz + (ysz >> 2)) : a_off;
-        if (any_f) rfh[h] = fetch_rows(gptr(pd.ref_fwd) + po, W, H, 8 * Rh + hi3, pxA, ayA, ohA, ovA, inA, hi3 == 7, useA);
-        if (TYPE == 3 && any_b) rbh[h] = fetch_rows(gptr(pd.ref_bwd) + po, W, H, 8 * Rh + hi3, pxB, ayB, ohB, ovB, inB, hi3 == 7, useB);
-    };
     if (TYPE != 1) {
-        fetch_half(0);
-        if (TYPE != 3 || !LEON_LATE_FETCH) fetch_half(1);
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+            const int Rh = CHROMA ? Rt : 2 * Rt + h;
+            const uint32_t po = CHROMA ? (h == 0 ? ysz : ysz + (ysz >> 2)) : a_off;
+            if (any_f) rfh[h] = fetch_rows(gptr(pd.ref_fwd) + po, W, H, 8 * Rh + hi3, pxA, ayA, ohA, ovA, inA, hi3 == 7, useA);
+            if (TYPE == 3 && any_b) rbh[h] = fetch_rows(gptr(pd.ref_bwd) + po, W, H, 8 * Rh + hi3, pxB, ayB, ohB, ovB, inB, hi3 == 7, useB);
+        }
     }
 
     // ---- stage 1: the tile [half][r][b][c] ---------------------------------------------------------
@@ -901,14 +860,13 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
         // floor( float(v) * _y ): the int16 the reference hands from pass 1 to pass 2
         const v2f k04 = {0.4f, 0.4f};
         const v2f s07 = co.p07 * k04, s16 = co.p16 * k04, s52 = co.p52 * k04, s43 = co.p43 * k04;
-        float wf[8] = {floorf(s07.x), floorf(s16.x), floorf(s52.y), floorf(s43.y),
-                       floorf(s43.x), floorf(s52.x), floorf(s16.y), floorf(s07.y)};
-        const float mx = fmaxf(fmaxf(fmaxf(fabsf(wf[0]), fabsf(wf[1])), fmaxf(fabsf(wf[2]), fabsf(wf[3]))),
-                               fmaxf(fmaxf(fabsf(wf[4]), fabsf(wf[5])), fmaxf(fabsf(wf[6]), fabsf(wf[7]))));
-        int wi[8];
-#pragma unroll
-        for (int n = 0; n < 8; n++) wi[n] = (int)wf[n];
-        if (mx > 32767.0f) {                              // outside any real stream: int16 wrap / saturation
+        // floor and conversion in one instruction (v_cvt_flr_i32_f32)
+        int wi[8] = {cvt_floor(s07.x), cvt_floor(s16.x), cvt_floor(s52.y), cvt_floor(s43.y),
+                     cvt_floor(s43.x), cvt_floor(s52.x), cvt_floor(s16.y), cvt_floor(s07.y)};
+        // |s| < 32768 for all eight: every floor(s) is an int16 as it stands
+        const float mx = fmaxf(fmaxf(fmaxf(fabsf(s07.x), fabsf(s16.x)), fmaxf(fabsf(s52.y), fabsf(s43.y))),
+                               fmaxf(fmaxf(fabsf(s43.x), fabsf(s52.x)), fmaxf(fabsf(s16.y), fabsf(s07.y))));
+        if (mx >= 32768.0f) {                             // outside any real stream: int16 wrap / saturation
 #pragma unroll
             for (int n = 0; n < 8; n++) wi[n] = handoff16(wi[n]);
         }
@@ -921,49 +879,35 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-    // ---- stage 3: row pass over the LIVE blocks of both halves -------------------------------------
-    // A block without a live column has zeros in the tile, and zeros are its residual: (0 + 128) / 256.  In P and B
-    // pictures two blocks in five carry coefficients, so the live blocks of both halves are queued like the columns
-    // were -- lane (n = hi3, j = lo3) takes row n of the j-th live block -- and one go usually does where there were
-    // two.  The residuals (t / 256, truncating, as saturated int16: |residual| > 255 behaves like 255) replace the
-    // hand-off values in place; stage 4 finds its eight in one read.
-    {
-        // lane (c, b) of the column masks -> bit c * 8 + b: fold the bytes for the blocks with any live column
-        uint64_t f0 = live[0], f1 = live[1];
-        f0 |= f0 >> 32; f1 |= f1 >> 32;
-        f0 |= f0 >> 16; f1 |= f1 >> 16;
-        f0 |= f0 >> 8;  f1 |= f1 >> 8;
-        const uint32_t blocks = ((uint32_t)f0 & 255u) | (((uint32_t)f1 & 255u) << 8);       // bit half * 8 + b
-        const uint32_t n_blk = (uint32_t)__builtin_popcount(blocks);
-        if (lane < 16 && ((blocks >> lane) & 1u))
-            *reinterpret_cast<uint8_t*>(lds + kOffSlots + __builtin_popcount(blocks & ((1u << lane) - 1u))) = (uint8_t)lane;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        // columns that are dead in every block of the task give zero inputs (wave-uniform)
-        const int cols_live = 8 - (__builtin_clzll(live[0] | live[1] | 1ull) >> 3);
-#pragma unroll 1
-        for (uint32_t base = 0; base < n_blk; base += 8u) {           // wave-uniform: once, twice for I pictures
-            const uint32_t j = base + (uint32_t)lo3;
-            const bool act = j < n_blk;
-            uint32_t id = *reinterpret_cast<const uint8_t*>(lds + kOffSlots + j);          // j <= 15
-            id = act ? id : 0u;
-            char* const rowp = lds + ((id & 8u) << 7) + hi3 * 128 + ((id & 7u) << 4);
-            const v4u wv = *reinterpret_cast<const v4u*>(rowp);
-            // int( w / _y ) == trunc(5w/2) == trunc(w * 2.5f): exact products, the conversion truncates
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        const uint32_t plane_off = CHROMA ? (half == 0 ? ysz : ysz + (ysz >> 2)) : a_off;
+        RefRows rf = rfh[half], rb = rbh[half];
+        int t[8];
+        const uint64_t colbits = live[half];
+        if (colbits == 0) {
+            // no coefficient in any of the 8 blocks: residual 0 = (0 + 128) / 256
+#pragma unroll
+            for (int m = 0; m < 8; m++) t[m] = 128;
+        } else {
+            // ---- stage 3: row pass ---------------------------------------------------------
+            // lane (n = hi3, b = lo3): row n of block b, eight int16 w; int( w / _y ) == trunc(5w/2) == trunc(w * 2.5f)
+            // (exact products, the conversion truncates).  Columns that are dead in every block of the half give
+            // zero inputs (wave-uniform): lane (c, b) of the liveness mask -> byte c
+            const int cols_live = 8 - (__builtin_clzll(colbits | 1ull) >> 3);
+            const v4u wv = *reinterpret_cast<const v4u*>(lds + half * kLdsHalf + hi3 * 128 + lo3 * 16);
             const v2f k25 = {2.5f, 2.5f};
-            const v2f a = v2f{half_to_float<0>(wv.x), half_to_float<1>(wv.x)} * k25;
+            const v2f a = v2f{(float)(short)(wv.x & 0xffffu), (float)((int)wv.x >> 16)} * k25;
             const int Y0 = (int)a.x + 128, Y1 = (int)a.y;                           // "+128" of (t+128)/256
-            int t[8];
             if (cols_live <= 2) {
                 butterfly8_lo2(Y0, Y1, t);
             } else {
-                const v2f bb = v2f{half_to_float<0>(wv.y), half_to_float<1>(wv.y)} * k25;
+                const v2f bb = v2f{(float)(short)(wv.y & 0xffffu), (float)((int)wv.y >> 16)} * k25;
                 if (cols_live <= 4) {
                     butterfly8_lo4(Y0, Y1, (int)bb.x, (int)bb.y, t);
                 } else {
-                    const v2f cc = v2f{half_to_float<0>(wv.z), half_to_float<1>(wv.z)} * k25;
-                    const v2f dd = v2f{half_to_float<0>(wv.w), half_to_float<1>(wv.w)} * k25;
+                    const v2f cc = v2f{(float)(short)(wv.z & 0xffffu), (float)((int)wv.z >> 16)} * k25;
+                    const v2f dd = v2f{(float)(short)(wv.w & 0xffffu), (float)((int)wv.w >> 16)} * k25;
                     const int Y[8] = {Y0, Y1, (int)bb.x, (int)bb.y, (int)cc.x, (int)cc.y, (int)dd.x, (int)dd.y};
                     butterfly8(Y, t);
                 }
@@ -971,28 +915,13 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
             // t/256 truncating == arithmetic shift after adding 255 to negative values.  Without a
             // prediction (I pictures) the difference between truncation and floor is invisible:
             // it only exists for negative t, which the final clamp turns into 0 either way.
+            if (TYPE != 1) {
 #pragma unroll
-            for (int m = 0; m < 8; m++) {
-                if (TYPE != 1) t[m] += (t[m] >> 31) & 255;
-                t[m] >>= 8;
+                for (int m = 0; m < 8; m++) t[m] += (t[m] >> 31) & 255;
             }
-            if (act)
-                *reinterpret_cast<v4u*>(rowp) = v4u{pack_sat16(t[0], t[1]), pack_sat16(t[2], t[3]), pack_sat16(t[4], t[5]), pack_sat16(t[6], t[7])};
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    }
 
-    if (TYPE == 3 && LEON_LATE_FETCH) fetch_half(1);
-#pragma unroll
-    for (int half = 0; half < 2; half++) {
-        const uint32_t plane_off = CHROMA ? (half == 0 ? ysz : ysz + (ysz >> 2)) : a_off;
-        RefRows rf = rfh[half], rb = rbh[half];
         // ---- stage 4: prediction, add, clamp, store ------------------------------------------
-        // lane (n = hi3, b = lo3): the eight residuals of row n of block b, four int16 pairs
-        const v4u rv = *reinterpret_cast<const v4u*>(lds + half * kLdsHalf + hi3 * 128 + lo3 * 16);
-        v2u o;
         if (TYPE != 1) {
             v2u pred = {0u, 0u};
             if (any_f) {
@@ -1011,13 +940,19 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
                 pred.y = __builtin_amdgcn_lerp(pf.y, pb.y, 0x01010101u);
             }
             if (nopred) pred = v2u{0u, 0u};
-            // clamp(residual + prediction) on int16 pairs
-            o.x = sat_u8x4(add_sat16x2(rv.x, pred_pair<0>(pred.x)), add_sat16x2(rv.y, pred_pair<1>(pred.x)));
-            o.y = sat_u8x4(add_sat16x2(rv.z, pred_pair<0>(pred.y)), add_sat16x2(rv.w, pred_pair<1>(pred.y)));
-        } else {
-            o.x = sat_u8x4(rv.x, rv.y);
-            o.y = sat_u8x4(rv.z, rv.w);
+            // clamp(t/256 + pred) == sat_u8((t + pred*256) >> 8)
+            t[0] += pred_x256<0>(pred.x);
+            t[1] += pred_x256<1>(pred.x);
+            t[2] += pred_x256<2>(pred.x);
+            t[3] += pred_x256<3>(pred.x);
+            t[4] += pred_x256<0>(pred.y);
+            t[5] += pred_x256<1>(pred.y);
+            t[6] += pred_x256<2>(pred.y);
+            t[7] += pred_x256<3>(pred.y);
         }
+        v2u o;
+        o.x = sat_pk4<8>(t[0], t[1], t[2], t[3]);
+        o.y = sat_pk4<8>(t[4], t[5], t[6], t[7]);
         if constexpr (!DISPLAY) {
             __builtin_amdgcn_raw_buffer_store_b64(o, buf_rsrc(pd.out + plane_off), (int)out_voff, (int)(half ? half_step : 0u), 0);
         } else {
@@ -1067,6 +1002,24 @@ __device__ __forceinline__ int xcd_remap(int bid, int n)
     return x * q + min(x, r) + j;
 }
 
+// workgroup -> (picture, workgroup inside the picture).  B pictures come in pairs that predict from the same two
+// anchors (the host keeps the pictures of a GOP adjacent): the workgroups of two consecutive pictures alternate, so
+// both read the same reference lines at about the same time and the second read finds them in the XCD's L2 -- one
+// after the other, a reference pair (6 MB at 1080p) is gone from the 4 MB L2 before it is used again.
+template <int TYPE>
+__device__ __forceinline__ void pic_of_wg(const Geom& G, int wg, int& pic, int& twg)
+{
+    if (TYPE == 3 && LEON_PAIR_B) {
+        const int half = wg >> 1;
+        const int pair = div_inv(half, G.inv_wg_per_pic);
+        twg = half - pair * G.wg_per_pic;
+        pic = 2 * pair + (wg & 1);
+    } else {
+        pic = div_inv(wg, G.inv_wg_per_pic);
+        twg = wg - pic * G.wg_per_pic;
+    }
+}
+
 template <int TYPE, bool SPARSE>
 __device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G, int t, char* lds, int lane)
 {
@@ -1096,9 +1049,10 @@ __global__ __launch_bounds__(kReconMaxThreads) void k_recon(const PicDesc* __res
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int wg = xcd_remap(blockIdx.x, G.n_wg);
-    const int pic = div_inv(wg, G.inv_wg_per_pic);
-    const int t = (wg - pic * G.wg_per_pic) * kWavesPerWG + wave;
-    if (t >= G.tasks_per_pic) return;
+    int pic, twg;
+    pic_of_wg<TYPE>(G, wg, pic, twg);
+    const int t = twg * kWavesPerWG + wave;
+    if (t >= G.tasks_per_pic || pic >= G.n_pics) return;
     char* lds = smem + wave * kLdsPerWave;
     stage_tables(T, lds, lane);
     recon_dispatch<TYPE, SPARSE>(descs[pic], G, t, lds, lane);
@@ -1118,8 +1072,9 @@ void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane = threadIdx.x & 63;
     const int wg = xcd_remap(blockIdx.x, G.n_wg);
-    const int pic = div_inv(wg, G.inv_wg_per_pic);
-    const int t = (wg - pic * G.wg_per_pic) * kWavesPerWG + wave;
+    int pic, twg;
+    pic_of_wg<TYPE>(G, wg, pic, twg);
+    const int t = twg * kWavesPerWG + wave;
     // the conversion tables: 5 KB per workgroup, requested before anything else and needed only after the
     // chroma part -- the barrier below finds them long landed.  Every wave takes part, with or without a task.
     __shared__ __attribute__((aligned(16))) int32_t lut_s[kLdsLut / 4];      // static: its LDS address is a compile-time constant
@@ -1132,7 +1087,7 @@ void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
 #pragma unroll
         for (int k = 0; k < 5; k++) dst[threadIdx.x + 256 * k] = v[k];
     }
-    const bool live = t < G.tasks_per_pic;
+    const bool live = t < G.tasks_per_pic && pic < G.n_pics;
     char* lds = smem + wave * (ALPHA ? kLdsPerWaveDisplayAlpha : kLdsPerWaveDisplay);
     const PicDesc& pd = descs[live ? pic : 0];
     const int Rt = div_inv(t, G.inv_gC), gc = t - Rt * G.gC;

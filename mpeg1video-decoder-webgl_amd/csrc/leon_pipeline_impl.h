@@ -81,13 +81,17 @@ struct leon_pipeline {
     std::vector<uint32_t> mine;                       // key-map ids this pipeline decodes (all, or g % shard_count == shard_index)
     uint64_t total_gops = 0;                          // gops * loop
     int W = 32, R = 2, K = 1, max_pics = 16;
+    bool unfused = false;        // frame_width % 8 != 0: planes for every picture, one display conversion launch per picture
     size_t frame_bytes = 0;
 
     leon_decoder* dec = nullptr;
     hipStream_t copy_stream = nullptr;
     uint8_t* d_rgba = nullptr;                        // R ring entries of W * max_pics frames
     bool gpu_parser = false;
-    hipStream_t vlc_stream = nullptr;                 // the parser kernels of window n + 1 run beside the reconstruction of window n
+    // The parser kernels of window n + 1 run beside the reconstruction of window n -- and beside the parser kernels of
+    // window n + 2, on a second stream: a parse launch lasts as long as its longest slice (one lane, symbol after symbol) and
+    // leaves three quarters of the issue slots idle; two of them side by side take little longer than one.
+    hipStream_t vlc_stream[2] = {nullptr, nullptr};
     leon::VlcTables* d_vlc_tables = nullptr;
     leon::VlcGeom vgeom{};
     std::vector<VlcRing> vlc_ring;
@@ -403,6 +407,7 @@ void parser_main(leon_pipeline* p)
 // (leon_vlc_gpu.h), on the decoder's stream, in front of the reconstruction launches that read their output
 int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
 {
+    hipStream_t vs = p->vlc_stream[(size_t)(w->id & 1)];
     size_t n_slices = 0, n_pics = 0;
     for (GopJob* job : w->jobs) { n_slices += job->slices.size(); n_pics += job->vpics.size(); }
     w->n_vpics = (uint32_t)n_pics;
@@ -453,27 +458,47 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
         }
         for (const leon::VlcPic& v : job->vpics) hp[pi++] = v;
     }
+    // Inside a type: picture by picture.  (LEON_VLC_ORDER=row puts the k-th slice of every picture side by side instead:
+    // the 64 lanes of a wave then hold slices that are alike, and a wave runs every block loop as long as its longest
+    // lane -- 30 % fewer instructions in all, and 25-30 % SLOWER end to end (round 3, both test streams): the launch
+    // has fewer waves than the chip has room for, it lasts as long as its longest wave, and a wave of 64 long slices is
+    // longer than a wave with one of them.)
+    static const bool by_row = getenv("LEON_VLC_ORDER") && !strcmp(getenv("LEON_VLC_ORDER"), "row");
     size_t si = 0;
-    for (int type = 1; type <= 3; type++)         // (by size inside a type as well: the sort costs the submit thread more than it saves)
+    for (int type = 1; type <= 3; type++) {
+        uint32_t longest = 0;
         for (const PicRun& pr : runs)
-            if (pr.type == type)
-                for (uint32_t k = 0; k < pr.n; k++) {
-                    hs[si] = pr.first[k];
-                    hs[si].pic = pr.pic;
-                    si++;
-                }
-    HIP_TRY(hipMemcpyAsync(R.d, R.h, desc_bytes, hipMemcpyHostToDevice, p->vlc_stream));
-    HIP_TRY(hipMemsetAsync(d_err, 0, n_pics * 4, p->vlc_stream));
+            if (pr.type == type) longest = std::max(longest, pr.n);
+        if (by_row) {
+            for (uint32_t k = 0; k < longest; k++)
+                for (const PicRun& pr : runs)
+                    if (pr.type == type && k < pr.n) {
+                        hs[si] = pr.first[k];
+                        hs[si].pic = pr.pic;
+                        si++;
+                    }
+        } else {
+            for (const PicRun& pr : runs)
+                if (pr.type == type)
+                    for (uint32_t k = 0; k < pr.n; k++) {
+                        hs[si] = pr.first[k];
+                        hs[si].pic = pr.pic;
+                        si++;
+                    }
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(R.d, R.h, desc_bytes, hipMemcpyHostToDevice, vs));
+    HIP_TRY(hipMemsetAsync(d_err, 0, n_pics * 4, vs));
     const leon::VlcClear* dc = (const leon::VlcClear*)(R.d + pad256(n_slices * sizeof(leon::VlcSlice)) + pad256(n_pics * sizeof(leon::VlcPic)));
-    hipLaunchKernelGGL(leon::k_vlc_clear, dim3(32, (unsigned)w->jobs.size()), dim3(256), 0, p->vlc_stream, dc);
+    hipLaunchKernelGGL(leon::k_vlc_clear, dim3(32, (unsigned)w->jobs.size()), dim3(256), 0, vs, dc);
     const leon::VlcSlice* ds = (const leon::VlcSlice*)R.d;
     const leon::VlcPic* dp = (const leon::VlcPic*)(R.d + pad256(n_slices * sizeof(leon::VlcSlice)));
     const int blocks = (int)((n_slices + 255) / 256);
-    hipLaunchKernelGGL(leon::k_vlc_parse, dim3(blocks), dim3(256), 0, p->vlc_stream, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
-    hipLaunchKernelGGL(leon::k_vlc_offsets, dim3((unsigned)n_pics), dim3(256), 0, p->vlc_stream, dp, p->vgeom);
-    hipLaunchKernelGGL(leon::k_vlc_gather, dim3((unsigned)((n_slices + 3) / 4)), dim3(256), 0, p->vlc_stream, ds, d_words, (int)n_slices, dp, p->vgeom);
+    hipLaunchKernelGGL(leon::k_vlc_parse, dim3(blocks), dim3(256), 0, vs, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
+    hipLaunchKernelGGL(leon::k_vlc_offsets, dim3((unsigned)n_pics), dim3(256), 0, vs, dp, p->vgeom);
+    hipLaunchKernelGGL(leon::k_vlc_gather, dim3((unsigned)((n_slices + 3) / 4)), dim3(256), 0, vs, ds, d_words, (int)n_slices, dp, p->vgeom, p->d_vlc_tables);
     HIP_TRY(hipGetLastError());
-    HIP_TRY(hipMemcpyAsync(R.h_err, d_err, n_pics * 4, hipMemcpyDeviceToHost, p->vlc_stream));
+    HIP_TRY(hipMemcpyAsync(R.h_err, d_err, n_pics * 4, hipMemcpyDeviceToHost, vs));
     return LEON_OK;
 }
 
@@ -496,16 +521,18 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
             p->st_upload += up;
         }
         int older = -1, newer = -1, lv_older = -1, lv_newer = -1, n_anchor = 0;      // anchor slots (0..2 of the lane) and their levels
+        const int per_lane = 3 + (p->unfused ? p->max_pics : 0);
+        int n_b = 0;
         for (const PipePic& m : job->pics) {
             Item it{j, &m, -1, -1, -1};
             int lv = 0;
             if (m.type == LEON_PIC_I) {
-                it.out = (int)(3 * j) + n_anchor % 3;
+                it.out = (int)(per_lane * j) + n_anchor % 3;
             } else if (m.type == LEON_PIC_P) {
                 if (newer < 0) return fail(LEON_ERR_INVALID, "GOP %llu: a P picture without a preceding anchor", (unsigned long long)job->gop);
                 it.fwd = newer;
                 lv = lv_newer + 1;
-                it.out = (int)(3 * j) + n_anchor % 3;
+                it.out = (int)(per_lane * j) + n_anchor % 3;
             } else {
                 if (newer < 0) return fail(LEON_ERR_INVALID, "GOP %llu: a B picture without an anchor (open GOPs cannot be sharded)", (unsigned long long)job->key_gop);
                 // the leading B pictures of a CLOSED GOP predict backward only (both references = the I picture); in an
@@ -516,6 +543,7 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
                 it.bwd = newer;
                 it.fwd = older >= 0 ? older : newer;
                 lv = std::max(lv_newer, lv_older) + 1;
+                if (p->unfused) it.out = (int)(per_lane * j) + 3 + n_b++ % p->max_pics;      // a slot of its own until it is converted
             }
             if (m.type != LEON_PIC_B) {
                 older = newer; lv_older = lv_newer;
@@ -538,13 +566,13 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
     HIP_TRY(hipEventRecord(copied, p->copy_stream));
     if (p->gpu_parser) {
         // upload -> parser kernels (their own stream) -> reconstruction (the decoder's stream)
-        HIP_TRY(hipStreamWaitEvent(p->vlc_stream, copied, 0));
+        HIP_TRY(hipStreamWaitEvent(p->vlc_stream[(size_t)(w->id & 1)], copied, 0));
         d->ev_pool.push_back(copied);
         const int rc = launch_gpu_parser(p, w);
         if (rc != LEON_OK) return rc;
         hipEvent_t parsed = get_event(d);
         if (!parsed) return LEON_ERR_HIP;
-        HIP_TRY(hipEventRecord(parsed, p->vlc_stream));
+        HIP_TRY(hipEventRecord(parsed, p->vlc_stream[(size_t)(w->id & 1)]));
         HIP_TRY(hipStreamWaitEvent(d->stream, parsed, 0));
         d->ev_pool.push_back(parsed);
     } else {
@@ -572,13 +600,18 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
             sp.mb_dir = (const uint8_t*)ptr(m.mb_dir);
             sp.mv_fwd = (const int16_t*)ptr(m.mv_fwd);
             sp.mv_bwd = (const int16_t*)ptr(m.mv_bwd);
-            sp.rgba_out = ring + ((size_t)it.lane * p->max_pics + (size_t)m.tref) * p->frame_bytes;
-            sp.no_planes = m.type == LEON_PIC_B;
+            sp.rgba_out = p->unfused ? nullptr : ring + ((size_t)it.lane * p->max_pics + (size_t)m.tref) * p->frame_bytes;
+            sp.no_planes = !p->unfused && m.type == LEON_PIC_B;
             batch.push_back(sp);
         }
         if (batch.empty()) continue;
         int rc = submit_batch_any(d, wrap(batch.data(), (int)batch.size()).data(), (int)batch.size(), LEON_MEM_DEVICE);
         if (rc != LEON_OK) return rc;
+        if (p->unfused)
+            for (const Item& it : lvl) {
+                rc = leon_convert_rgba(d, it.out, ring + ((size_t)it.lane * p->max_pics + (size_t)it.pic->tref) * p->frame_bytes, LEON_MEM_DEVICE, LEON_RGB_CPU_TWIN);
+                if (rc != LEON_OK) return rc;
+            }
     }
     HIP_TRY(hipEventRecord(w->done, d->stream));
     // frames in display order, GOP-major
@@ -802,8 +835,27 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
     p->total_gops = (uint64_t)p->mine.size() * (uint64_t)loops;
     p->W = cfg->gops_per_window > 0 ? cfg->gops_per_window : 32;
     if ((uint64_t)p->W > p->total_gops) p->W = (int)p->total_gops;
-    p->R = cfg->windows_in_flight > 0 ? cfg->windows_in_flight : (cfg->gpu_parser ? 3 : 2);      // GPU parser: one window being parsed beside one reconstructed and one read
-    p->max_pics = cfg->max_gop_pictures > 0 ? cfg->max_gop_pictures : 16;
+    p->gpu_parser = cfg->gpu_parser >= 0;          // 0 = default: the GPU (a pipeline has a device by construction); < 0: the parser threads
+    p->R = cfg->windows_in_flight > 0 ? cfg->windows_in_flight : (p->gpu_parser ? 3 : 2);      // GPU parser: one window being parsed beside one reconstructed and one read
+    if (cfg->max_gop_pictures > 0) p->max_pics = cfg->max_gop_pictures;
+    else {
+        // the frames a GOP can fill in a window's ring entry: the longest GOP of this pipeline's shards, from the picture
+        // start codes (00 00 01 00 -- the syntax keeps that pattern out of everything else); a fixed 16 would reserve a
+        // third more than IBBP-12 streams use
+        size_t longest = 1;
+        for (uint64_t g : p->mine) {
+            const uint8_t* b = stream + p->shard_begin[g];
+            const uint8_t* const e = stream + p->shard_end[g];
+            size_t n = 0;
+            while (b + 4 <= e) {
+                const uint8_t* z = (const uint8_t*)memchr(b, 0, (size_t)(e - b) - 3);
+                if (!z) break;
+                if (z[1] == 0 && z[2] == 1 && z[3] == 0) { n++; b = z + 4; } else b = z + 1;
+            }
+            longest = std::max(longest, n);
+        }
+        p->max_pics = (int)std::min<size_t>(longest, 1024);
+    }
     int k = cfg->parser_threads;
     if (k <= 0) { k = (int)std::thread::hardware_concurrency(); if (k < 1) k = 1; if (k > 16) k = 16; }
     p->K = k;
@@ -815,12 +867,16 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
     p->info.gops = (uint32_t)p->shard_begin.size();
     p->info.shard_gops = (uint32_t)p->mine.size();
     p->info.parser_threads = p->K; p->info.gops_per_window = p->W;
-    if (p->vinfo.frame_width & 7) { delete p; return fail(LEON_ERR_INVALID, "the pipeline needs frame_width %% 8 == 0 (it is %d)", p->vinfo.frame_width); }
+    // the fused display conversion writes eight pixels per lane: it needs frame_width % 8 == 0.  The reference crops to
+    // any width (player/easybits.player.js:2818): such a stream takes the slow road -- every picture (B pictures too)
+    // writes its planes, and one leon_convert_rgba per picture (the generic k_rgba_twin) fills the window's frames.
+    p->unfused = (p->vinfo.frame_width & 7) != 0;
+    if (p->unfused && p->vinfo.has_alpha == 1) { delete p; return fail(LEON_ERR_INVALID, "a yuva stream needs frame_width %% 8 == 0 in the pipeline (it is %d)", p->vinfo.frame_width); }
 
     leon_config dc{};
     dc.coded_width = p->vinfo.coded_width; dc.coded_height = p->vinfo.coded_height;
     dc.frame_width = p->vinfo.frame_width; dc.frame_height = p->vinfo.frame_height;
-    dc.n_slots = 3 * p->W;
+    dc.n_slots = (3 + (p->unfused ? p->max_pics : 0)) * p->W;      // three rotating anchors per GOP of a window (+ its B pictures)
     dc.alpha = p->vinfo.has_alpha == 1;        // yuva: the frames' A bytes come from the stream's fourth component
     dc.device_id = cfg->device_id;
     int rc = leon_create(&dc, &p->dec);
@@ -833,9 +889,13 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
     };
     if (rc != LEON_OK) { leon_pipeline_destroy(p); return rc; }
     if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(LEON_ERR_HIP, "copy stream");
-    if (hipMalloc((void**)&p->d_rgba, (size_t)p->R * p->W * p->max_pics * p->frame_bytes) != hipSuccess) return bail(LEON_ERR_NOMEM, "RGBA ring");
+    if (hipMalloc((void**)&p->d_rgba, (size_t)p->R * p->W * p->max_pics * p->frame_bytes) != hipSuccess) {
+        const std::string what = "RGBA ring of " + std::to_string((size_t)p->R * p->W * p->max_pics * p->frame_bytes >> 20) + " MiB (windows_in_flight " +
+                                 std::to_string(p->R) + " x gops_per_window " + std::to_string(p->W) + " x max_gop_pictures " + std::to_string(p->max_pics) +
+                                 " x " + std::to_string(p->frame_bytes) + " bytes per frame)";
+        return bail(LEON_ERR_NOMEM, what.c_str());
+    }
     p->ring_owner.assign((size_t)p->R, -1);
-    p->gpu_parser = cfg->gpu_parser != 0;
     if (p->gpu_parser) {
         // the front end's tables in the order the kernels copy them to LDS (leon_vlc_gpu.h)
         std::vector<leon_vlc_gpu_tables> src(1);
@@ -856,8 +916,17 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
         for (int i = 0; i < 128; i++) t[0].dc_lum[i] = pack(src[0].dc_lum[i]);
         for (int i = 0; i < 256; i++) t[0].dc_chr[i] = pack(src[0].dc_chr[i]);
         for (int i = 0; i < 64; i++) t[0].zz_off[i] = src[0].zz_off[i];
-        memcpy(t[0].coef16, src[0].coef16, sizeof(t[0].coef16));
-        if (hipStreamCreateWithFlags(&p->vlc_stream, hipStreamNonBlocking) != hipSuccess) return bail(LEON_ERR_HIP, "parser stream");
+        // the codes of 12 .. 16 bits start with seven zeros: by the nine bits behind them (= the first 512 entries of the
+        // 16-bit table)
+        for (int i = 0; i < 512; i++) {
+            const int32_t e = src[0].coef16[i];
+            const int len = e >> 16, cf = e & 0xffff, run = cf >> 8, level = cf & 0xff;
+            if (e == 0) { t[0].long9[i] = 0; continue; }
+            if (cf == 0xffff || len < 8 || len > 16 || run > 31 || level > 63 || level == 0) { leon_pipeline_destroy(p); return fail(LEON_ERR_INVALID, "long coefficient code does not fit 16 bits"); }
+            t[0].long9[i] = (uint16_t)(len | (run << 5) | (level << 10));
+        }
+        for (hipStream_t& vs : p->vlc_stream)
+            if (hipStreamCreateWithFlags(&vs, hipStreamNonBlocking) != hipSuccess) return bail(LEON_ERR_HIP, "parser stream");
         if (hipMalloc((void**)&p->d_vlc_tables, sizeof(leon::VlcTables)) != hipSuccess) return bail(LEON_ERR_NOMEM, "GPU parser tables");
         if (hipMemcpy(p->d_vlc_tables, t.data(), sizeof(leon::VlcTables), hipMemcpyHostToDevice) != hipSuccess) return bail(LEON_ERR_HIP, "GPU parser tables");
         p->vgeom.mbw = p->vinfo.mb_width; p->vgeom.mbh = p->vinfo.mb_height;
@@ -988,7 +1057,8 @@ void leon_pipeline_destroy(leon_pipeline* p)
         if (r.h_err) hipHostFree(r.h_err);
     }
     if (p->d_vlc_tables) hipFree(p->d_vlc_tables);
-    if (p->vlc_stream) hipStreamDestroy(p->vlc_stream);
+    for (hipStream_t vs : p->vlc_stream)
+        if (vs) hipStreamDestroy(vs);
     if (p->d_rgba) hipFree(p->d_rgba);
     if (p->copy_stream) hipStreamDestroy(p->copy_stream);
     if (p->dec) leon_destroy(p->dec);

@@ -33,18 +33,20 @@ namespace leon {
 
 // Device copy of the front end's tables (leon_vlc_get_gpu_tables), the LDS part first and in 16 bits:
 //   fast12: bits 0..3 length (0 = longer code or escape), bit 4 end of block, bits 5..9 run, bits 10..15 level
+//   long9:  the codes of 12 .. 16 bits (all of them start with seven zeros) by the nine bits behind those zeros:
+//           bits 0..4 length without the sign bit, bits 5..9 run, bits 10..15 level (unsigned), 0 = invalid code
 //   the others: (length << 8) | value, 0 = invalid code
 struct VlcTables {
     uint16_t fast12[4096];
+    uint16_t long9[512];
     uint16_t motion_s[2048];
     uint16_t mba[2048];
     uint16_t cbp[512];
     uint16_t mbtype[4][64];
     uint16_t dc_lum[128], dc_chr[256];
     uint16_t zz_off[64];
-    int32_t coef16[65536];       // stays in global memory: long codes and escapes only
 };
-static constexpr int kVlcLdsWords = (4096 + 2048 + 2048 + 512 + 256 + 128 + 256 + 64) / 2;
+static constexpr int kVlcLdsWords = (4096 + 512 + 2048 + 2048 + 512 + 256 + 128 + 256 + 64) / 2;
 // every lane reads its slice through a ring of 16 dwords in LDS: dword i of lane L at ring[(i & 15) * 64 + L]
 static constexpr int kVlcRingDwords = 16;
 static constexpr int kVlcRingBytesPerWave = kVlcRingDwords * 64 * 4;
@@ -108,12 +110,14 @@ struct VlcWin {
     uint64_t w;                  // the stream from `pos` on, left aligned, `avail` bits valid, zeros below
     int avail;
     uint32_t pos;                // in bits, from base
+    uint32_t ahead;              // dword `next` of the stream, already out of the ring: a refill of the window never waits for LDS
     uint32_t* ring;              // this wave's ring (LDS), already offset by the lane
     __device__ __forceinline__ void request(uint32_t* wave_ring, int lane, uint32_t upto)      // dwords [loaded, upto), upto - next <= 16
     {
         vlc_request(base, loaded, upto, nd, wave_ring, lane);
         loaded = upto;
     }
+    __device__ __forceinline__ uint32_t slot(uint32_t i) const { return __builtin_bswap32(ring[(i & 15u) * 64u]); }
     __device__ __forceinline__ void init(const uint32_t* b, uint32_t n_dwords, uint32_t bit_pos, uint32_t* wave_ring, int lane)
     {
         base = b; nd = n_dwords; pos = bit_pos;
@@ -123,14 +127,19 @@ struct VlcWin {
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         safe = loaded;
         const uint32_t lead = bit_pos & 31u;
-        const uint32_t d0 = take(), d1 = take();
+        const uint32_t d0 = slot(next), d1 = slot(next + 1u);
+        next += 2u;
+        ahead = slot(next);
         w = (((uint64_t)d0 << 32) | d1) << lead;
         avail = 64 - (int)lead;
     }
+    // the next dword of the stream; its successor is fetched from the ring at once and is long there when it is wanted
+    // (read where it is needed, the LDS latency sat on the path of every symbol: some lane of the 64 refills at every step)
     __device__ __forceinline__ uint32_t take()
     {
-        const uint32_t d = __builtin_bswap32(ring[(next & 15u) * 64u]);
+        const uint32_t d = ahead;
         next++;
+        ahead = slot(next);
         return d;
     }
     // Top-up point (wave-uniform): called in front of every syntax element; between two calls a lane takes at most one
@@ -138,7 +147,7 @@ struct VlcWin {
     // (requested half a ring ago), then request up to a full ring again.
     __device__ __forceinline__ void sync(uint32_t* wave_ring, int lane)
     {
-        const bool low = loaded - next < 8u || safe - next < 2u;
+        const bool low = loaded - next < 8u || safe - next < 3u;      // take() reads dword next + 1
         if (__builtin_amdgcn_ballot_w64(low) != 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             safe = loaded;
@@ -167,6 +176,7 @@ struct VlcWin {
 
 struct VlcLds {
     uint16_t fast12[4096];
+    uint16_t long9[512];
     uint16_t motion_s[2048];
     uint16_t mba[2048];
     uint16_t cbp[512];
@@ -232,7 +242,9 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
         gid = (uint32_t)(G.n_y + (COMP == 2 ? G.n_c : 0) + c.mb_row * G.gc + (c.mb_col >> 3));
         bq = (uint32_t)(c.mb_col & 7);
     }
-    const uint32_t boff = (bq * 16u) << 16;
+    // an entry as k_vlc_parse leaves it: (block of the group * 64 + zig-zag index) << 16 | level; k_vlc_gather turns the
+    // index into the tile offset of include/leon_vlc.h on its way (the table lookup was an LDS round trip per symbol here)
+    const uint32_t bbase = (bq * 64u) << 16;
     if (c.hdr >= c.hdr_end || c.ent + 64 > c.ent_end) return VLC_ERR_SCRATCH;      // a block: one header, at most 64 entries
     VLC_G uint32_t* const rec = c.ent;
     int k = 0, n = 0;
@@ -252,7 +264,7 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
                                                     : predictor + ((int)(0xffffffffu << size) | (differential + 1));
         }
         if (COMP == 0) c.dc_y = dc; else if (COMP == 3) c.dc_a = dc; else if (COMP == 1) c.dc_cr = dc; else c.dc_cb = dc;
-        if ((int16_t)dc != 0) rec[k++] = boff | (uint16_t)(int16_t)dc;
+        if ((int16_t)dc != 0) rec[k++] = bbase | (uint16_t)(int16_t)dc;
         n = 1;
     }
     // the first symbol of a non-intra block: '1s' is run 0, level +-1 (two bits), and there is no end-of-block code.
@@ -264,7 +276,7 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
         const uint32_t p2 = r.peek(2);
         if (p2 & 2u) {
             r.drop(2);
-            rec[k++] = boff | (uint32_t)(uint16_t)(int16_t)((p2 & 1u) ? -1 : 1);      // zig-zag position 0: tile offset 0
+            rec[k++] = bbase | (uint32_t)(uint16_t)(int16_t)((p2 & 1u) ? -1 : 1);      // zig-zag position 0
             n = 1;
         }
     }
@@ -280,13 +292,12 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
             run_len = (int)((f >> 5) & 31u);
             level = (int)(int16_t)(uint16_t)f >> 10;
         } else {
-            // longer codes and escapes
+            // escapes ('0000 01', read arithmetically) and the codes of 12 .. 16 bits (seven zeros in front; a second
+            // table in LDS).  (Through the 16-bit table in global memory, a wave waited for memory in one iteration
+            // of six: some lane of the 64 is here.)
             const uint64_t w = r.w;
-            const int32_t e = ((const VLC_G int32_t*)T->coef16)[w >> 48];
-            if (e == 0) return VLC_ERR_COEF;
-            const int len = e >> 16, coeff = e & 0xffff;
             int used;
-            if (coeff == 0xffff) {                           // escape: 6-bit run, 8- or 16-bit level
+            if ((w >> 58) == 1u) {                           // escape: 6-bit run, 8- or 16-bit level
                 run_len = (int)((w >> 52) & 63);
                 level = (int)((w >> 44) & 255);
                 used = 20;
@@ -294,8 +305,12 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
                 else if (level == 128) { level = (int)((w >> 36) & 255) - 256; used = 28; }
                 else if (level > 128) level -= 256;
             } else {
-                run_len = coeff >> 8;
-                level = coeff & 0xff;
+                if ((w >> 57) != 0u) return VLC_ERR_COEF;
+                const uint32_t e = L.long9[(uint32_t)(w >> 48) & 511u];
+                if (e == 0u) return VLC_ERR_COEF;
+                const int len = (int)(e & 31u);
+                run_len = (int)((e >> 5) & 31u);
+                level = (int)(e >> 10);
                 if ((w >> (63 - len)) & 1) level = -level;
                 used = len + 1;
             }
@@ -303,8 +318,8 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
         }
         n += run_len;
         if (n > 63) return VLC_ERR_INDEX;
-        const uint32_t zo = L.zz_off[n++];
-        if (level != 0) rec[k++] = boff | (zo << 16) | (uint16_t)(int16_t)level;
+        if (level != 0) rec[k++] = bbase | ((uint32_t)n << 16) | (uint16_t)(int16_t)level;
+        n++;
     }
     if (r.pos > (uint32_t)(r.nd << 5)) return VLC_ERR_END;     // ran off the data (zeros behind it: an invalid code ended the loop at the latest)
     if (k) {
@@ -537,9 +552,12 @@ __global__ __launch_bounds__(256) void k_vlc_offsets(const VlcPic* __restrict__ 
 }
 
 __global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__ slices, const uint32_t* __restrict__ slice_blocks, int n_slices,
-                                                    const VlcPic* __restrict__ pics, VlcGeom G)
+                                                    const VlcPic* __restrict__ pics, VlcGeom G, const VlcTables* __restrict__ T)
 {
     __shared__ uint32_t s_from[4][65], s_at[4][64];                  // per wave: where the round's blocks start in the strip, where they go
+    __shared__ uint16_t s_zz[64];                                    // zig-zag index -> byte offset of the coefficient in its block's part of the tile
+    if (threadIdx.x < 64) s_zz[threadIdx.x] = T->zz_off[threadIdx.x];
+    __syncthreads();
     const int wv = (int)(threadIdx.x >> 6);
     const int j = blockIdx.x * 4 + wv;                               // one wave per slice
     const int lane = threadIdx.x & 63;
@@ -596,7 +614,11 @@ __global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__
             for (uint32_t step = 32; step != 0; step >>= 1)
                 if (s_from[wv][lo + step] <= e) lo += step;
             const uint32_t dst = s_at[wv][lo];
-            if (dst != 0xffffffffu) entries[dst + (e - s_from[wv][lo])] = ent[e];
+            if (dst != 0xffffffffu) {
+                // (block * 64 + zig-zag index) -> the tile offset block * 16 + zz_off[index]
+                const uint32_t v = ent[e], hi = v >> 16;
+                entries[dst + (e - s_from[wv][lo])] = ((((hi >> 6) & 7u) * 16u + s_zz[hi & 63u]) << 16) | (v & 0xffffu);
+            }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();

@@ -387,7 +387,7 @@ class Pipeline:
     released right after.  read_frame(frame) works until the frame's window is released."""
 
     def __init__(self, data, device_id=0, parser_threads=0, gops_per_window=0, windows_in_flight=0, max_gop_pictures=0,
-                 loop=0, on_window=None, shard_index=0, shard_count=0, start_seconds=0.0, gpu_parser=False):
+                 loop=0, on_window=None, shard_index=0, shard_count=0, start_seconds=0.0, gpu_parser=None):
         self.lib = load()
         self._data = (C.c_uint8 * len(data)).from_buffer_copy(data)      # must outlive the pipeline
         self._on_window = on_window
@@ -430,7 +430,7 @@ class Pipeline:
         self._cb = PIPELINE_CB(_cb)
         self._ready = ready
         cfg = PipelineConfig(device_id, parser_threads, gops_per_window, windows_in_flight, max_gop_pictures, loop,
-                             shard_index, shard_count, float(start_seconds), 1 if gpu_parser else 0, 0)
+                             shard_index, shard_count, float(start_seconds), 0 if gpu_parser is None else (1 if gpu_parser else -1), 0)      # None: the library's default (the GPU)
         h = C.c_void_p()
         self.h = None
         rc = self.lib.leon_pipeline_create(C.byref(cfg), self._data, len(data), self._cb, None, C.byref(h))

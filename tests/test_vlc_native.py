@@ -335,3 +335,47 @@ def test_corruption_fuzz_under_address_and_ub_sanitizers(tmp_path):
     r = subprocess.run([exe] + streams, capture_output=True, text=True, timeout=600, env=dict(os.environ, LEON_FUZZ_CASES="150"))
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     assert "refused" in r.stdout
+
+
+def test_merged_gops_parse_like_the_parts():
+    """jsv_writer.merge_gops: GOPs written as separate single-GOP streams (by parallel processes, for the long 1080p
+    stream of tools/stream_1080p.py) and merged parse to the same pictures as the parts, the key map points at each GOP's
+    sequence header and the GOP time codes count on"""
+    import jsv_writer as W
+    import synth as S
+    cw, ch = 96, 64
+    parts, want = [], []
+    for g, n in enumerate([6, 9, 3]):
+        rng = np.random.default_rng([5, g])
+        pics = []
+        for ptype, disp, f, b in S.gop_ibbp(n):
+            t = S.make_picture(rng, cw, ch, ptype, force_dir=2 if (ptype == S.PIC_B and f is None) else None)
+            t["display"] = disp
+            pics.append(t)
+        data = W.write_stream(pics, cw, ch, cw, ch, gop_starts=[0])[0]
+        parts.append(data)
+        st = V.Stream(data, threads=1)
+        while True:
+            p = st.next_picture(dense=True)
+            if p is None:
+                break
+            want.append(p)
+        st.close()
+    merged, offs = W.merge_gops(parts, cw, ch)
+    st = V.Stream(merged, threads=1)
+    assert list(st.keymap()) == offs and len(offs) == 3
+    got = []
+    while True:
+        p = st.next_picture(dense=True)
+        if p is None:
+            break
+        got.append(p)
+    assert len(got) == len(want) == 18
+    for a, b in zip(got, want):
+        assert a["type"] == b["type"] and a["temporal_reference"] == b["temporal_reference"]
+        for k in ("coef_y", "coef_cb", "coef_cr", "qscale", "intra", "repadd", "mv_fwd", "mv_bwd", "mb_dir"):
+            if b.get(k) is not None:
+                assert np.array_equal(a[k], b[k]), k
+    # time codes: GOP 1 starts 6 pictures in, GOP 2 15 pictures in (25 pictures/s)
+    firsts = [p["ts"] for p in got if p["type"] == 1]
+    assert firsts[0] < firsts[1] < firsts[2] and abs((firsts[1] - firsts[0]) - 6 * 40.0) < 1e-6 and abs((firsts[2] - firsts[0]) - 15 * 40.0) < 1e-6

@@ -25,7 +25,7 @@ const t0 = process.hrtime.bigint();
 const p = new LeonPipeline(stream, { parserThreads: opt('--threads', 0), gopsPerWindow: opt('--window', 0),
                                      windowsInFlight: opt('--inflight', 0), loop: opt('--loop', 0), autoRelease: !hash,
                                      deviceId: opt('--device', 0), shardIndex: opt('--shard-index', 0), shardCount: opt('--shard-count', 0),
-                                     gpuParser: process.argv.includes('--gpu-parser') ? 1 : 0 });
+                                     gpuParser: process.argv.includes('--gpu-parser') ? 1 : -1 });
 p.on('frames', (w, fs_) => {
   windows++;
   frames += fs_.length;

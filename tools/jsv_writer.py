@@ -396,3 +396,50 @@ def write_stream(pictures, cw, ch, frame_w=None, frame_h=None, rate_idx=3, gop_s
             hdr.put(tc & 0xffffffff, 32)
     assert len(hdr.buf) == n_hdr, (len(hdr.buf), n_hdr)
     return bytes(hdr.buf) + bytes(body.buf), [o + n_hdr for o, _ in offsets]
+
+
+def merge_gops(streams, frame_w, frame_h, rate_idx=3, alpha=False):
+    """One stream from several single-GOP streams (each written by write_stream with key_map=True and gop_starts=[0],
+    same picture size and rate): the bodies back to back, the GOP headers' time codes counted on, one container header
+    with a key map over all of them.  Lets the GOPs of a long stream be written by parallel processes."""
+    rate = [0, 23.976, 24, 25, 29.97, 30, 50, 59.94, 60][rate_idx]
+    bodies, offsets, frame_no = [], [], 0
+    at = 0
+    for i, data in enumerate(streams):
+        data = bytes(data)
+        if data[:2] != b"\x6a\x73" or data[11:15] != bytes([0, 0, 1, START_MAP]) or int.from_bytes(data[15:19], "big") != 1:
+            raise ValueError("stream %d is not a single-GOP stream with a key map" % i)
+        body = bytearray(data[27:])
+        tail = bytes([0, 0, 1, START_END]) + bytes(8)
+        if bytes(body[-12:]) != tail:
+            raise ValueError("stream %d does not end with the end code" % i)
+        if i + 1 < len(streams):
+            del body[-12:]
+        g = bytes(body[:256]).find(bytes([0, 0, 1, START_GOP]))
+        if g < 0:
+            raise ValueError("stream %d: no GOP header behind the sequence header" % i)
+        sec = int(frame_no / rate)
+        tc = ((sec // 3600) << 26) | (((sec // 60) % 60) << 20) | (1 << 19) | ((sec % 60) << 13) | ((int(frame_no - sec * rate) & 63) << 7) | (1 << 6)
+        body[g + 4:g + 8] = tc.to_bytes(4, "big")             # time code, closed_gop = 1, broken_link = 0, padding
+        offsets.append((at, frame_no))
+        at += len(body)
+        bodies.append(bytes(body))
+        # pictures of this GOP: picture start codes 00 00 01 00
+        frame_no += bytes(body).count(bytes([0, 0, 1, START_PICTURE]))
+    hdr = BitWriter()
+    hdr.put(0x6A73, 16)
+    hdr.put(frame_w, 16)
+    hdr.put(frame_h, 16)
+    hdr.put(0, 16)
+    hdr.put(1 if alpha else 0, 1)
+    hdr.put(int(round(frame_no / rate * 100)), 23)
+    n_hdr = 11 + 8 + 8 * len(offsets)
+    hdr.buf += bytes([0, 0, 1, START_MAP])
+    hdr.put(len(offsets), 32)
+    for off, fno in offsets:
+        hdr.put(off + n_hdr, 32)
+        sec = int(fno / rate)
+        tc = ((sec // 3600) << 26) | (((sec // 60) % 60) << 20) | (1 << 19) | ((sec % 60) << 13) | ((int(fno - sec * rate) & 63) << 7)
+        hdr.put(tc & 0xffffffff, 32)
+    assert len(hdr.buf) == n_hdr
+    return bytes(hdr.buf) + b"".join(bodies), [o + n_hdr for o, _ in offsets]

@@ -29,9 +29,14 @@ def main():
     ap.add_argument("--window", type=int, default=32)
     ap.add_argument("--inflight", type=int, default=2)
     ap.add_argument("--gpu-parser", action="store_true", help="decode the slice layer on the GPU (leon_pipeline_config.gpu_parser)")
+    ap.add_argument("--varied", action="store_true", help="the 16-GOP stream with 16 different contents (tools/stream_1080p.py) instead of --gops GOPs")
     a = ap.parse_args()
     cached = os.path.join(ROOT, "tools", "probe", "stream_1080p_%dgop.bin" % a.gops)
-    if os.path.exists(cached):
+    if a.varied:
+        import stream_1080p
+        data = stream_1080p.load_varied()
+        a.gops = stream_1080p.VARIED_GOPS
+    elif os.path.exists(cached):
         data = open(cached, "rb").read()
     else:
         import parse_bench
@@ -55,7 +60,8 @@ def main():
         "parser_pictures_per_s_per_thread": s["pictures"] / s["parse_seconds_sum"] if s["parse_seconds_sum"] else None,
         "upload_gb": s["upload_bytes"] / 1e9, "upload_gbps": s["upload_bytes"] / 1e9 / s["seconds"],
         "entries_per_picture": s["entries"] / max(1, s["pictures"]), "stream_bytes": s["stream_bytes"],
-        "stream_megabit_per_picture": s["stream_bytes"] * 8 / 1e6 / (12 * a.gops), "host_threads": os.cpu_count()}))
+        "stream_megabit_per_picture": s["stream_bytes"] * 8 / 1e6 / (12 * a.gops), "host_threads": os.cpu_count(),
+        "stream": "%d different GOPs, looped %d times" % (a.gops, a.loop), "slice_order": os.environ.get("LEON_VLC_ORDER", "row")}))
 
 
 if __name__ == "__main__":

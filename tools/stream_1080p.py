@@ -37,5 +37,56 @@ def load():
     return open(ensure(), "rb").read()
 
 
+
+
+# ---- the varied stream: N different GOPs, written by parallel processes and merged (jsv_writer.merge_gops) -------------
+VARIED_GOPS = 16
+VARIED_PATH = os.path.join(ROOT, "tools", "probe", "stream_1080p_%dgop_varied.bin" % VARIED_GOPS)
+
+
+def _one_gop(g):
+    for p in (os.path.join(ROOT, "mpeg1video-decoder-webgl_amd"), os.path.join(ROOT, "tools")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import numpy as np
+    import jsv_writer as W
+    import synth as S
+    rng = np.random.default_rng([0x4C454F4E, 1080, g])
+    pics = []
+    for ptype, disp, f, b in S.gop_ibbp(12):
+        t = S.make_picture(rng, 1920, 1088, ptype, force_dir=2 if (ptype == S.PIC_B and f is None) else None)
+        t["display"] = disp
+        pics.append(t)
+    return W.write_stream(pics, 1920, 1088, 1920, 1080, gop_starts=[0])[0]
+
+
+def ensure_varied(path=VARIED_PATH, n_gops=VARIED_GOPS, workers=None):
+    """N closed IBBP GOPs with N different contents (GOP g is seeded by (0x4C454F4E, 1080, g)): what the end-to-end figures
+    should be quoted on -- on the 2-GOP stream looped, a launch of the GPU parser holds every slice dozens of times, and
+    lanes with identical slices do not diverge.  Written by `workers` processes (one GOP each, 15 s per GOP)."""
+    if os.path.exists(path) and os.path.getsize(path) > n_gops * 1000000:
+        return path
+    import multiprocessing as mp
+    for p in (os.path.join(ROOT, "mpeg1video-decoder-webgl_amd"), os.path.join(ROOT, "tools")):
+        if p not in sys.path:
+            sys.path.insert(0, p)
+    import jsv_writer as W
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    workers = max(1, min(workers or ncpu, n_gops))
+    with mp.get_context("spawn").Pool(workers) as pool:
+        gops = pool.map(_one_gop, range(n_gops))
+    data, _ = W.merge_gops(gops, 1920, 1080)
+    tmp = path + ".tmp%d" % os.getpid()
+    open(tmp, "wb").write(data)
+    os.replace(tmp, path)
+    return path
+
+
+def load_varied():
+    return open(ensure_varied(), "rb").read()
+
+
 if __name__ == "__main__":
     print(ensure())
+    if "--varied" in sys.argv:
+        print(ensure_varied())
