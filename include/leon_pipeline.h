@@ -100,6 +100,16 @@ typedef struct leon_pipeline_stats {
 /* Copies nothing: `stream` must stay valid until leon_pipeline_destroy.  Starts decoding at once. */
 int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream, size_t bytes,
                          leon_pipeline_callback cb, void* user, leon_pipeline** out);
+/* The same for a stream that is still arriving -- the reference's decoder consumes a growing buffer, stalls when it runs
+ * dry and resumes when a chunk is appended (features/bitreader.js:332-430 addBuffer, :135-189 has; decoders/jsv.js
+ * :426-469): `stream` is the buffer for the WHOLE file (`bytes` = its final size, known from the HTTP headers as in the
+ * reference's {data, start, end, total} chunks), of which the first `valid_bytes` are there -- enough for the container
+ * header, the key map and the first sequence header.  The loader writes on into the same buffer and reports progress
+ * with leon_pipeline_feed(p, valid_bytes_now); a GOP is parsed once the bytes up to the next key-map entry have
+ * arrived, windows are delivered as they complete.  With max_gop_pictures <= 0 a partial stream reserves 16 frames per GOP. */
+int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t* stream, size_t bytes, size_t valid_bytes,
+                                 leon_pipeline_callback cb, void* user, leon_pipeline** out);
+int leon_pipeline_feed(leon_pipeline* p, size_t valid_bytes);
 int leon_pipeline_get_info(leon_pipeline* p, leon_pipeline_info* out);
 /* the consumer is done with a window's frames: its RGBA ring entry and staging may be reused */
 int leon_pipeline_release_window(leon_pipeline* p, int64_t window);

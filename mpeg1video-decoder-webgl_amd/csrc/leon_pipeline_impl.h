@@ -74,6 +74,7 @@ struct leon_pipeline {
     leon_pipeline_info info{};
     const uint8_t* stream = nullptr;
     size_t bytes = 0;
+    size_t valid = 0;            // how much of the stream has arrived (leon_pipeline_feed); under mu
     leon_pipeline_callback cb = nullptr;
     void* user = nullptr;
     leon_vlc_info vinfo{};
@@ -81,6 +82,7 @@ struct leon_pipeline {
     std::vector<uint32_t> mine;                       // key-map ids this pipeline decodes (all, or g % shard_count == shard_index)
     uint64_t total_gops = 0;                          // gops * loop
     int W = 32, R = 2, K = 1, max_pics = 16;
+    uint64_t st_wait_ring_ns = 0, st_wait_scan_ns = 0;       // submit thread: waiting for a ring entry / for the window's GOPs to be parsed
     bool unfused = false;        // frame_width % 8 != 0: planes for every picture, one display conversion launch per picture
     size_t frame_bytes = 0;
 
@@ -391,8 +393,22 @@ void parser_main(leon_pipeline* p)
         GopJob* job = new GopJob();
         job->gop = g;
         job->arena = a;
+        {   // a stream that is still arriving (leon_pipeline_create_partial): the GOP's bytes must be there -- the
+            // decoder of the reference stalls the same way when its buffer runs dry (features/bitreader.js:135-189)
+            const uint64_t need = p->shard_end[p->mine[g % p->mine.size()]];
+            std::unique_lock<std::mutex> lk(p->mu);
+            p->cv.wait(lk, [&] { return p->stop || p->valid >= need; });
+            if (p->stop) { p->free_arenas.push_back(a); delete job; return; }
+        }
+        {
+            const uint8_t* b = p->stream + p->shard_begin[p->mine[g % p->mine.size()]];
+            if (b[0] != 0 || b[1] != 0 || b[2] != 1) {
+                job->status = LEON_ERR_INVALID;
+                job->err = "key map entry " + std::to_string(p->mine[g % p->mine.size()]) + " does not point at a start code";
+            }
+        }
         const auto t = Clock::now();
-        parse_gop(p, job);
+        if (job->status == LEON_OK) parse_gop(p, job);
         p->st_parse_ns += (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(Clock::now() - t).count();
         {
             std::lock_guard<std::mutex> lk(p->mu);
@@ -403,11 +419,18 @@ void parser_main(leon_pipeline* p)
 }
 
 
+// which of the two parser streams a window's parser kernels run on (LEON_VLC_STREAMS=1: all on one, for A/B runs)
+inline size_t vlc_stream_of(int64_t window)
+{
+    static const bool one = getenv("LEON_VLC_STREAMS") && atoi(getenv("LEON_VLC_STREAMS")) == 1;
+    return one ? 0 : (size_t)(window & 1);
+}
+
 // gpu_parser: the slices of the whole window in one launch each of k_vlc_parse / k_vlc_offsets / k_vlc_gather
-// (leon_vlc_gpu.h), on the decoder's stream, in front of the reconstruction launches that read their output
+// (leon_vlc_gpu.h), on a parser stream, in front of the reconstruction launches that read their output
 int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
 {
-    hipStream_t vs = p->vlc_stream[(size_t)(w->id & 1)];
+    hipStream_t vs = p->vlc_stream[vlc_stream_of(w->id)];
     size_t n_slices = 0, n_pics = 0;
     for (GopJob* job : w->jobs) { n_slices += job->slices.size(); n_pics += job->vpics.size(); }
     w->n_vpics = (uint32_t)n_pics;
@@ -566,13 +589,13 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
     HIP_TRY(hipEventRecord(copied, p->copy_stream));
     if (p->gpu_parser) {
         // upload -> parser kernels (their own stream) -> reconstruction (the decoder's stream)
-        HIP_TRY(hipStreamWaitEvent(p->vlc_stream[(size_t)(w->id & 1)], copied, 0));
+        HIP_TRY(hipStreamWaitEvent(p->vlc_stream[vlc_stream_of(w->id)], copied, 0));
         d->ev_pool.push_back(copied);
         const int rc = launch_gpu_parser(p, w);
         if (rc != LEON_OK) return rc;
         hipEvent_t parsed = get_event(d);
         if (!parsed) return LEON_ERR_HIP;
-        HIP_TRY(hipEventRecord(parsed, p->vlc_stream[(size_t)(w->id & 1)]));
+        HIP_TRY(hipEventRecord(parsed, p->vlc_stream[vlc_stream_of(w->id)]));
         HIP_TRY(hipStreamWaitEvent(d->stream, parsed, 0));
         d->ev_pool.push_back(parsed);
     } else {
@@ -654,6 +677,8 @@ void submit_loop(leon_pipeline* p)
     for (int64_t wid = 0; wid < p->total_windows; wid++) {
         PipeWindow* w = new PipeWindow();
         w->id = wid;
+        const auto t_begin = Clock::now();
+        auto t_ring = t_begin, t_scanned = t_begin;
         const uint64_t g0 = (uint64_t)wid * p->W, g1 = std::min<uint64_t>(g0 + p->W, p->total_gops);
         {
             std::unique_lock<std::mutex> lk(p->mu);
@@ -665,6 +690,7 @@ void submit_loop(leon_pipeline* p)
                 return false;
             });
             if (p->stop) { delete w; return; }
+            t_ring = Clock::now();
             for (int r = 0; r < p->R; r++)
                 if (p->ring_owner[r] < 0) { w->ring = r; p->ring_owner[r] = wid; break; }
             p->cv.wait(lk, [&] {
@@ -674,6 +700,7 @@ void submit_loop(leon_pipeline* p)
                 return true;
             });
             if (p->stop) { delete w; return; }
+            t_scanned = Clock::now();
             for (uint64_t g = g0; g < g1; g++) {
                 w->jobs.push_back(p->parsed[g]);
                 p->parsed.erase(g);
@@ -693,6 +720,11 @@ void submit_loop(leon_pipeline* p)
             }
         }
         w->status = rc;
+        {   // where the submit thread's time goes, per window (LEON_PIPE_TRACE=1 prints it when the pipeline is destroyed)
+            const auto ns = [](Clock::time_point a, Clock::time_point b) { return (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(b - a).count(); };
+            p->st_wait_ring_ns += ns(t_begin, t_ring);
+            p->st_wait_scan_ns += ns(t_ring, t_scanned);
+        }
         if (rc != LEON_OK) pipe_fail(p, rc, msg);
         {
             std::lock_guard<std::mutex> lk(p->mu);
@@ -785,10 +817,30 @@ extern "C" {
 int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream, size_t bytes,
                          leon_pipeline_callback cb, void* user, leon_pipeline** out)
 {
+    return leon_pipeline_create_partial(cfg, stream, bytes, bytes, cb, user, out);
+}
+
+int leon_pipeline_feed(leon_pipeline* p, size_t valid_bytes)
+{
+    if (!p) return fail(LEON_ERR_INVALID, "null pipeline");
+    if (valid_bytes > p->bytes) return fail(LEON_ERR_INVALID, "%zu bytes fed, the stream has %zu", valid_bytes, p->bytes);
+    {
+        std::lock_guard<std::mutex> lk(p->mu);
+        if (valid_bytes > p->valid) p->valid = valid_bytes;
+    }
+    p->cv.notify_all();
+    return LEON_OK;
+}
+
+int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t* stream, size_t bytes, size_t valid_bytes,
+                                 leon_pipeline_callback cb, void* user, leon_pipeline** out)
+{
     if (!cfg || !stream || bytes < 16 || !out) return fail(LEON_ERR_INVALID, "null argument");
+    if (valid_bytes > bytes) return fail(LEON_ERR_INVALID, "%zu valid bytes of a stream of %zu", valid_bytes, bytes);
     *out = nullptr;
     leon_vlc_stream* st = nullptr;
-    if (leon_vlc_open(stream, bytes, 1, &st) != LEON_VLC_OK) return fail(LEON_ERR_INVALID, "stream: %s", leon_vlc_last_error());
+    // the container header, the key map and the first sequence header must have arrived
+    if (leon_vlc_open(stream, valid_bytes, 1, &st) != LEON_VLC_OK) return fail(LEON_ERR_INVALID, "stream: %s", leon_vlc_last_error());
     leon_pipeline* p = new (std::nothrow) leon_pipeline();
     if (!p) { leon_vlc_close(st); return fail(LEON_ERR_NOMEM, "out of host memory"); }
     leon_vlc_get_info(st, &p->vinfo);
@@ -806,12 +858,14 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
     p->cfg = *cfg;
     p->stream = stream;
     p->bytes = bytes;
+    p->valid = valid_bytes;
     p->cb = cb;
     p->user = user;
     if (n_keys > 0) {
         for (int g = 0; g < n_keys; g++) {
             const uint64_t b = offs[(size_t)g], e = g + 1 < n_keys ? offs[(size_t)g + 1] : bytes;
-            if (b >= e || e > bytes || b + 4 > bytes || stream[b] != 0 || stream[b + 1] != 0 || stream[b + 2] != 1) {
+            // (an entry behind what has arrived of a partial stream is looked at when its bytes are there: parser_main)
+            if (b >= e || e > bytes || b + 4 > bytes || (b + 4 <= valid_bytes && (stream[b] != 0 || stream[b + 1] != 0 || stream[b + 2] != 1))) {
                 delete p;
                 return fail(LEON_ERR_INVALID, "key map entry %d does not point at a start code", g);
             }
@@ -838,6 +892,7 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
     p->gpu_parser = cfg->gpu_parser >= 0;          // 0 = default: the GPU (a pipeline has a device by construction); < 0: the parser threads
     p->R = cfg->windows_in_flight > 0 ? cfg->windows_in_flight : (p->gpu_parser ? 3 : 2);      // GPU parser: one window being parsed beside one reconstructed and one read
     if (cfg->max_gop_pictures > 0) p->max_pics = cfg->max_gop_pictures;
+    else if (valid_bytes < bytes) p->max_pics = 16;          // still arriving: nothing to count yet
     else {
         // the frames a GOP can fill in a window's ring entry: the longest GOP of this pipeline's shards, from the picture
         // start codes (00 00 01 00 -- the syntax keeps that pattern out of everything else); a fixed 16 would reserve a
@@ -925,8 +980,14 @@ int leon_pipeline_create(const leon_pipeline_config* cfg, const uint8_t* stream,
             if (cf == 0xffff || len < 8 || len > 16 || run > 31 || level > 63 || level == 0) { leon_pipeline_destroy(p); return fail(LEON_ERR_INVALID, "long coefficient code does not fit 16 bits"); }
             t[0].long9[i] = (uint16_t)(len | (run << 5) | (level << 10));
         }
+        // The parser kernels want little of the chip (a quarter of the issue slots of the SIMDs they sit on) but all of it
+        // for as long as their longest slice takes; the reconstruction launches beside them fill every CU.  Highest
+        // stream priority: a freed slot goes to a waiting parser workgroup first.  (LEON_VLC_PRIO=0: default priority.)
+        int prio_lo = 0, prio_hi = 0;
+        hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+        const bool high = !(getenv("LEON_VLC_PRIO") && atoi(getenv("LEON_VLC_PRIO")) == 0);
         for (hipStream_t& vs : p->vlc_stream)
-            if (hipStreamCreateWithFlags(&vs, hipStreamNonBlocking) != hipSuccess) return bail(LEON_ERR_HIP, "parser stream");
+            if (hipStreamCreateWithPriority(&vs, hipStreamNonBlocking, high ? prio_hi : prio_lo) != hipSuccess) return bail(LEON_ERR_HIP, "parser stream");
         if (hipMalloc((void**)&p->d_vlc_tables, sizeof(leon::VlcTables)) != hipSuccess) return bail(LEON_ERR_NOMEM, "GPU parser tables");
         if (hipMemcpy(p->d_vlc_tables, t.data(), sizeof(leon::VlcTables), hipMemcpyHostToDevice) != hipSuccess) return bail(LEON_ERR_HIP, "GPU parser tables");
         p->vgeom.mbw = p->vinfo.mb_width; p->vgeom.mbh = p->vinfo.mb_height;
@@ -1049,7 +1110,10 @@ void leon_pipeline_destroy(leon_pipeline* p)
         delete a;
     }
     if (getenv("LEON_DEBUG_PIPE_TIMING"))      // where the submit thread's time went (LEON_DEBUG_PIPE_TIMING=1)
-        fprintf(stderr, "leon pipeline: %llu windows, submit_window %.1f ms per window on the host\n", (unsigned long long)p->windows_submitted,
+        fprintf(stderr, "leon pipeline: %llu windows; per window on the submit thread: %.2f ms waiting for a ring entry, %.2f ms waiting for the window's GOPs "
+                        "(parser threads), %.2f ms in submit_window\n", (unsigned long long)p->windows_submitted,
+                p->windows_submitted ? (double)p->st_wait_ring_ns / 1e6 / (double)p->windows_submitted : 0.0,
+                p->windows_submitted ? (double)p->st_wait_scan_ns / 1e6 / (double)p->windows_submitted : 0.0,
                 p->windows_submitted ? (double)p->st_submit_ns.load() / 1e6 / (double)p->windows_submitted : 0.0);
     for (VlcRing& r : p->vlc_ring) {
         if (r.h) hipHostFree(r.h);

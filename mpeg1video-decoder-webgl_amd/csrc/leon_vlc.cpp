@@ -211,11 +211,19 @@ struct Bits {
         return e & 0xffff;
     }
     // byte-aligned scan for 00 00 01 xx; returns xx with pos behind it, or -1 at the end
+    // the next 00 00 01 xx at or behind the current byte: memchr finds the 01s (one byte in 256 of a video stream) at
+    // memory speed, the two bytes in front of a hit decide.  (Byte by byte, the picture layer scan of the GPU parser's
+    // host side spent most of its 80 us per 1080p picture here.)
     int next_start_code()
     {
-        size_t i = (pos + 7) >> 3;
-        for (; i + 3 < nbytes; i++) {
-            if (b[i] == 0 && b[i + 1] == 0 && b[i + 2] == 1) { pos = (i + 4) << 3; return b[i + 3]; }
+        const size_t i = (pos + 7) >> 3;
+        size_t j = i + 2;                                   // where a start code's 01 may sit
+        while (j + 1 < nbytes) {
+            const uint8_t* q = (const uint8_t*)memchr(b + j, 1, nbytes - 1 - j);
+            if (!q) break;
+            j = (size_t)(q - b);
+            if (b[j - 1] == 0 && b[j - 2] == 0) { pos = (j + 2) << 3; return b[j + 1]; }
+            j++;
         }
         pos = nbytes * 8;
         return -1;

@@ -110,14 +110,15 @@ struct VlcWin {
     uint64_t w;                  // the stream from `pos` on, left aligned, `avail` bits valid, zeros below
     int avail;
     uint32_t pos;                // in bits, from base
-    uint32_t ahead;              // dword `next` of the stream, already out of the ring: a refill of the window never waits for LDS
+    uint32_t ahead;              // dword `next` of the stream as it lies in memory (big endian), already out of the ring: a refill of the window never waits for LDS
     uint32_t* ring;              // this wave's ring (LDS), already offset by the lane
     __device__ __forceinline__ void request(uint32_t* wave_ring, int lane, uint32_t upto)      // dwords [loaded, upto), upto - next <= 16
     {
         vlc_request(base, loaded, upto, nd, wave_ring, lane);
         loaded = upto;
     }
-    __device__ __forceinline__ uint32_t slot(uint32_t i) const { return __builtin_bswap32(ring[(i & 15u) * 64u]); }
+    __device__ __forceinline__ uint32_t raw(uint32_t i) const { return ring[(i & 15u) * 64u]; }
+    __device__ __forceinline__ uint32_t slot(uint32_t i) const { return __builtin_bswap32(raw(i)); }
     __device__ __forceinline__ void init(const uint32_t* b, uint32_t n_dwords, uint32_t bit_pos, uint32_t* wave_ring, int lane)
     {
         base = b; nd = n_dwords; pos = bit_pos;
@@ -129,7 +130,7 @@ struct VlcWin {
         const uint32_t lead = bit_pos & 31u;
         const uint32_t d0 = slot(next), d1 = slot(next + 1u);
         next += 2u;
-        ahead = slot(next);
+        ahead = raw(next);
         w = (((uint64_t)d0 << 32) | d1) << lead;
         avail = 64 - (int)lead;
     }
@@ -137,14 +138,16 @@ struct VlcWin {
     // (read where it is needed, the LDS latency sat on the path of every symbol: some lane of the 64 refills at every step)
     __device__ __forceinline__ uint32_t take()
     {
-        const uint32_t d = ahead;
+        const uint32_t d = __builtin_bswap32(ahead);      // swapped when it is used: the read below is not waited for here
         next++;
-        ahead = slot(next);
+        ahead = raw(next);
         return d;
     }
     // Top-up point (wave-uniform): called in front of every syntax element; between two calls a lane takes at most one
     // dword.  When any lane is down to half a ring, or to its last landed dwords: wait for what is on its way
-    // (requested half a ring ago), then request up to a full ring again.
+    // (requested half a ring ago), then request up to a full ring again.  (Requesting without the wait and waiting only
+    // when a lane is about to read what has not been waited for -- so that the wait sees the stores of the last symbols
+    // instead of the loads, gfx950 counts both on one counter -- measured no faster.)
     __device__ __forceinline__ void sync(uint32_t* wave_ring, int lane)
     {
         const bool low = loaded - next < 8u || safe - next < 3u;      // take() reads dword next + 1

@@ -50,6 +50,9 @@ class LeonPipeline extends EventEmitter {
     if (this.autoRelease) this._p.releaseWindow(window);
   }
 
+  // a stream that is still arriving (opts.validBytes at construction; the Buffer has the file's final size): the loader
+  // writes the next chunk into the same Buffer and reports how far it is valid now -- features/bitreader.js:332 addBuffer
+  feed(validBytes) { this._p.feed(validBytes); }
   readFrame(window, index) { return this._p.readFrame(window, index); }
   releaseWindow(window) { this._p.releaseWindow(window); }
   stats() { return this._p.stats(); }

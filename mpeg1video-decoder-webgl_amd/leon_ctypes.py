@@ -31,7 +31,7 @@ SYMBOLS = [
 ]
 # include/leon_pipeline.h (same library)
 PIPELINE_SYMBOLS = [
-    "leon_pipeline_create", "leon_pipeline_get_info", "leon_pipeline_release_window", "leon_pipeline_wait",
+    "leon_pipeline_create", "leon_pipeline_create_partial", "leon_pipeline_feed", "leon_pipeline_get_info", "leon_pipeline_release_window", "leon_pipeline_wait",
     "leon_pipeline_get_stats", "leon_pipeline_read_frame", "leon_pipeline_error", "leon_pipeline_destroy",
 ]
 
@@ -159,6 +159,8 @@ def load():
     lib.leon_timing_get_launches.argtypes = [C.c_void_p, C.POINTER(LaunchTime), C.c_int32, C.POINTER(C.c_int32)]
     lib.leon_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double)]
     lib.leon_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.c_void_p, C.c_size_t, PIPELINE_CB, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.leon_pipeline_create_partial.argtypes = [C.POINTER(PipelineConfig), C.c_void_p, C.c_size_t, C.c_size_t, PIPELINE_CB, C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.leon_pipeline_feed.argtypes = [C.c_void_p, C.c_size_t]
     lib.leon_pipeline_get_info.argtypes = [C.c_void_p, C.POINTER(PipelineInfo)]
     lib.leon_pipeline_release_window.argtypes = [C.c_void_p, C.c_int64]
     lib.leon_pipeline_wait.argtypes = [C.c_void_p]
@@ -387,7 +389,7 @@ class Pipeline:
     released right after.  read_frame(frame) works until the frame's window is released."""
 
     def __init__(self, data, device_id=0, parser_threads=0, gops_per_window=0, windows_in_flight=0, max_gop_pictures=0,
-                 loop=0, on_window=None, shard_index=0, shard_count=0, start_seconds=0.0, gpu_parser=None):
+                 loop=0, on_window=None, shard_index=0, shard_count=0, start_seconds=0.0, gpu_parser=None, valid_bytes=None):
         self.lib = load()
         self._data = (C.c_uint8 * len(data)).from_buffer_copy(data)      # must outlive the pipeline
         self._on_window = on_window
@@ -433,7 +435,11 @@ class Pipeline:
                              shard_index, shard_count, float(start_seconds), 0 if gpu_parser is None else (1 if gpu_parser else -1), 0)      # None: the library's default (the GPU)
         h = C.c_void_p()
         self.h = None
-        rc = self.lib.leon_pipeline_create(C.byref(cfg), self._data, len(data), self._cb, None, C.byref(h))
+        # valid_bytes: the stream is still arriving (leon_pipeline_create_partial); feed() reports progress
+        if valid_bytes is None:
+            rc = self.lib.leon_pipeline_create(C.byref(cfg), self._data, len(data), self._cb, None, C.byref(h))
+        else:
+            rc = self.lib.leon_pipeline_create_partial(C.byref(cfg), self._data, len(data), int(valid_bytes), self._cb, None, C.byref(h))
         _chk(rc)
         self.h = h
         info = PipelineInfo()
@@ -446,6 +452,12 @@ class Pipeline:
         out = np.empty((self.info.frame_height, self.info.frame_width, 4), dtype=np.uint8)
         _chk(self.lib.leon_pipeline_read_frame(self.h, C.byref(frame["_frames"][frame["_i"]]), out.ctypes.data))
         return out
+
+    def feed(self, valid_bytes, chunk=None, offset=None):
+        """more of the stream has arrived: optionally copy `chunk` to `offset` of the pipeline's buffer first"""
+        if chunk is not None:
+            C.memmove(C.addressof(self._data) + int(offset), bytes(chunk), len(chunk))
+        _chk(self.lib.leon_pipeline_feed(self.h, int(valid_bytes)))
 
     def release_window(self, window):
         _chk(self.lib.leon_pipeline_release_window(self.h, window))

@@ -537,6 +537,20 @@ napi_value PipeDestroy(napi_env env, napi_callback_info info)
     return nullptr;
 }
 
+// feed(validBytes): more of the stream has arrived in the Buffer the pipeline was created on
+napi_value PipeFeed(napi_env env, napi_callback_info info)
+{
+    size_t argc = 1;
+    napi_value argv[1], self;
+    NAPI_OK(napi_get_cb_info(env, info, &argc, argv, &self, nullptr));
+    PipeHandle* h = nullptr;
+    if (napi_unwrap(env, self, (void**)&h) != napi_ok || !h || !h->p) { napi_throw_error(env, nullptr, "pipeline destroyed"); return nullptr; }
+    int64_t v = -1;
+    if (argc < 1 || napi_get_value_int64(env, argv[0], &v) != napi_ok || v < 0) { napi_throw_type_error(env, nullptr, "feed(validBytes)"); return nullptr; }
+    const int rc = leon_pipeline_feed(h->p, (size_t)v);
+    return rc == LEON_OK ? nullptr : throw_leon(env, rc);
+}
+
 napi_value CreatePipeline(napi_env env, napi_callback_info info)
 {
     size_t argc = 3;
@@ -583,7 +597,12 @@ napi_value CreatePipeline(napi_env env, napi_callback_info info)
         return nullptr;
     }
     napi_create_reference(env, argv[0], 1, &h->stream_ref);
-    int rc = leon_pipeline_create(&cfg, (const uint8_t*)data, len, pipe_native_cb, h, &h->p);
+    // validBytes: the stream is still arriving (leon_pipeline_create_partial) -- the loader writes on into the same
+    // Buffer and calls feed(validBytesNow), as addBuffer does in the reference (features/bitreader.js:332-430)
+    int32_t valid = -1;
+    get_i32(env, argv[1], "validBytes", &valid, -1);
+    int rc = valid >= 0 ? leon_pipeline_create_partial(&cfg, (const uint8_t*)data, len, (size_t)valid, pipe_native_cb, h, &h->p)
+                        : leon_pipeline_create(&cfg, (const uint8_t*)data, len, pipe_native_cb, h, &h->p);
     if (rc != LEON_OK) {
         napi_release_threadsafe_function(h->tsfn, napi_tsfn_abort);
         napi_delete_reference(env, h->stream_ref);
@@ -595,7 +614,7 @@ napi_value CreatePipeline(napi_env env, napi_callback_info info)
     NAPI_OK(napi_create_object(env, &obj));
     NAPI_OK(napi_wrap(env, obj, h, pipe_finalize, nullptr, nullptr));
     const struct { const char* name; napi_callback fn; } methods[] = {
-        {"releaseWindow", PipeRelease}, {"readFrame", PipeReadFrame}, {"stats", PipeStats}, {"destroy", PipeDestroy}};
+        {"releaseWindow", PipeRelease}, {"readFrame", PipeReadFrame}, {"stats", PipeStats}, {"destroy", PipeDestroy}, {"feed", PipeFeed}};
     for (auto& m : methods) {
         napi_value fn;
         NAPI_OK(napi_create_function(env, m.name, NAPI_AUTO_LENGTH, m.fn, nullptr, &fn));

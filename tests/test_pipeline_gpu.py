@@ -191,6 +191,57 @@ def test_frame_widths_that_are_no_multiple_of_8(L, gpu_parser):
             assert bad.size == 0, "frame %s differs in %d bytes, first at %s" % (k, len(bad), bad[0])
 
 
+@pytest.mark.parametrize("gpu_parser", [False, True], ids=["host-parser", "gpu-parser"])
+def test_a_stream_that_is_still_arriving(L, gpu_parser):
+    """leon_pipeline_create_partial + leon_pipeline_feed: the reference's decoder works on a growing buffer, stalls when
+    it runs dry and goes on when a chunk is appended (features/bitreader.js:332-430, :135-189).  The pipeline is created
+    on the container header + key map + one GOP; the other GOPs arrive in pieces that ignore GOP boundaries; frames
+    come as their GOPs complete and equal the oracle's"""
+    import time
+    import leon_vlc_ctypes as V
+    data = ibbp_stream(96, 64, [6, 9, 3, 12, 6], seed=77)
+    want = oracle_frames(data)
+    offs = V.Stream(data, threads=1).keymap()
+    got, lock = {}, threading.Lock()
+
+    def on_window(window, frames):
+        with lock:
+            for f in frames:
+                got[(f["gop"], f["display_index"])] = L.read_frame(f)
+    first = offs[1] + 3                     # GOP 0 complete (a shard takes the start code prefix of what follows along)
+    buf = bytearray(len(data))
+    buf[:first] = data[:first]
+    pipe = L.Pipeline(bytes(buf), parser_threads=2, gops_per_window=1, gpu_parser=gpu_parser, on_window=on_window, valid_bytes=first)
+    try:
+        t0 = time.time()
+        while time.time() - t0 < 20:
+            with lock:
+                if len([k for k in got if k[0] == 0]) == 6:
+                    break
+            time.sleep(0.01)
+        with lock:
+            assert sorted(k for k in got) == sorted(k for k in want if k[0] == 0), "GOP 0 decodes while the rest of the stream is still missing"
+        time.sleep(0.05)
+        with lock:
+            assert all(k[0] == 0 for k in got)          # nothing of what has not arrived
+        at = first
+        for step in (500, 1, 1800, 700, 10 ** 9):
+            n = min(step, len(data) - at)
+            pipe.feed(at + n, data[at:at + n], at)
+            at += n
+            if at == len(data):
+                break
+        pipe.wait()
+    finally:
+        pipe.close()
+    assert set(got) == set(want)
+    for k in want:
+        assert np.array_equal(got[k], want[k]), k
+    # feeding backwards or beyond the end is refused / ignored
+    with pytest.raises(L.LeonError):
+        L.Pipeline(data, valid_bytes=len(data) + 1)
+
+
 def test_pipeline_errors(L):
     with pytest.raises(L.LeonError):
         L.Pipeline(b"\x00" * 64)

@@ -22,9 +22,17 @@ for a, b, _ in rows[1:]:
     if a > cur_b: busy += cur_b - cur_a; cur_a, cur_b = a, b
     else: cur_b = max(cur_b, b)
 busy += cur_b - cur_a
+# idle gaps of the whole device: how long, and which kernel ended them
+gaps = collections.defaultdict(lambda: [0, 0])
+end = rows[0][1]
+for a, b, k in rows[1:]:
+    if a > end:
+        gaps[k][0] += 1; gaps[k][1] += a - end
+    end = max(end, b)
 bench = json.loads(open(out + "/bench.json").read().strip().splitlines()[-1])
-n_parse = per.get("k_vlc_parse", [1, 0])[0]
+n_parse = max(1, max([v[0] for k, v in per.items() if "k_vlc_parse" in k] + [1]))
 res = {"pictures_per_s": bench["value"], "windows": n_parse, "span_ms": (t1 - t0) / 1e6, "gpu_busy_ms": busy / 1e6, "ms_per_window": (t1 - t0) / 1e6 / max(1, n_parse),
+       "idle_before": {k: {"gaps": v[0], "total_ms": round(v[1] / 1e6, 2)} for k, v in sorted(gaps.items(), key=lambda x: -x[1][1])},
        "kernels": {k: {"launches": v[0], "total_ms": round(v[1] / 1e6, 2), "avg_ms": round(v[1] / 1e6 / v[0], 3), "ms_per_window": round(v[1] / 1e6 / max(1, n_parse), 3)} for k, v in sorted(per.items(), key=lambda x: -x[1][1])}}
 json.dump(res, open(out + "/summary.json", "w"), indent=1)
 print(json.dumps(res, indent=1)[:3000])
