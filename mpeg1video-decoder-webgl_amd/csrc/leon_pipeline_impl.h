@@ -986,8 +986,19 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
         int prio_lo = 0, prio_hi = 0;
         hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
         const bool high = !(getenv("LEON_VLC_PRIO") && atoi(getenv("LEON_VLC_PRIO")) == 0);
-        for (hipStream_t& vs : p->vlc_stream)
-            if (hipStreamCreateWithPriority(&vs, hipStreamNonBlocking, high ? prio_hi : prio_lo) != hipSuccess) return bail(LEON_ERR_HIP, "parser stream");
+        // LEON_VLC_CUS=K: the parser streams may use K compute units only (hipExtStreamCreateWithCUMask; the first K bits of
+        // the mask).  Packed four waves to a SIMD on a part of the chip, the parser leaves the rest to the reconstruction
+        // launches at their full occupancy instead of thinning them out everywhere.
+        const int cus = getenv("LEON_VLC_CUS") ? atoi(getenv("LEON_VLC_CUS")) : 0;
+        for (hipStream_t& vs : p->vlc_stream) {
+            hipError_t e;
+            if (cus > 0) {
+                uint32_t mask[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+                for (int i = 0; i < cus && i < 256; i++) mask[i >> 5] |= 1u << (i & 31);
+                e = hipExtStreamCreateWithCUMask(&vs, 8, mask);
+            } else e = hipStreamCreateWithPriority(&vs, hipStreamNonBlocking, high ? prio_hi : prio_lo);
+            if (e != hipSuccess) return bail(LEON_ERR_HIP, "parser stream");
+        }
         if (hipMalloc((void**)&p->d_vlc_tables, sizeof(leon::VlcTables)) != hipSuccess) return bail(LEON_ERR_NOMEM, "GPU parser tables");
         if (hipMemcpy(p->d_vlc_tables, t.data(), sizeof(leon::VlcTables), hipMemcpyHostToDevice) != hipSuccess) return bail(LEON_ERR_HIP, "GPU parser tables");
         p->vgeom.mbw = p->vinfo.mb_width; p->vgeom.mbh = p->vinfo.mb_height;

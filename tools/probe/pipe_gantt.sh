@@ -3,7 +3,7 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=$1; shift
 mkdir -p $out
-timeout -k 10 300 rocprofv3 --kernel-trace -d $out/kt --output-format csv -- python3 tools/pipeline_bench.py --gpu-parser --threads 16 --window 128 --inflight 3 "$@" > $out/bench.json 2> $out/err.log || echo "trace failed"
+timeout -k 10 300 rocprofv3 --kernel-trace -d $out/kt --output-format csv -- python3 tools/pipeline_bench.py --gpu-parser --threads 16 --inflight 3 "$@" > $out/bench.json 2> $out/err.log || echo "trace failed"
 python3 - $out <<'PY'
 import csv, glob, sys
 out = sys.argv[1]
