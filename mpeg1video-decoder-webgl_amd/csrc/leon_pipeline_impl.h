@@ -234,7 +234,7 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
         }
         ecap[k] = std::min(std::max(pic_words, (size_t)64), max_entries);
         need += gpad + pad256(ecap[k] * 4 + 4);
-        for (size_t c : scap[k]) need += pad256((2 * c + 8 + 4 * c + 64) * 4);
+        for (size_t c : scap[k]) need += pad256((2 * c + 8) * leon::kVlcRecWords * 4);
     }
     if (!arena_reserve(p, a_of(job), stream_pad, need)) { job->status = LEON_ERR_NOMEM; job->err = "staging allocation failed"; return; }
     Arena* a = job->arena;
@@ -287,8 +287,8 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
             sl.pic = (uint32_t)k;
             // a coded block takes at least four bits (one header), an entry at least two
             sl.hdr_cap = (uint32_t)(2 * scap[k][j] + 8);
-            sl.ent_cap = (uint32_t)(4 * scap[k][j] + 64);
-            sl.scratch = (uint32_t*)(dev + take(pad256(((size_t)sl.hdr_cap + sl.ent_cap) * 4)));
+            sl.ent_cap = 0;
+            sl.scratch = (uint32_t*)(dev + take(pad256((size_t)sl.hdr_cap * leon::kVlcRecWords * 4)));
             job->slices.push_back(sl);
         }
     }
@@ -426,7 +426,7 @@ inline size_t vlc_stream_of(int64_t window)
     return one ? 0 : (size_t)(window & 1);
 }
 
-// gpu_parser: the slices of the whole window in one launch each of k_vlc_parse / k_vlc_offsets / k_vlc_gather
+// gpu_parser: the slices of the whole window in one launch each of k_vlc_parse / k_vlc_offsets / k_vlc_blocks
 // (leon_vlc_gpu.h), on a parser stream, in front of the reconstruction launches that read their output
 int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
 {
@@ -519,7 +519,7 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
     const int blocks = (int)((n_slices + 255) / 256);
     hipLaunchKernelGGL(leon::k_vlc_parse, dim3(blocks), dim3(256), 0, vs, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
     hipLaunchKernelGGL(leon::k_vlc_offsets, dim3((unsigned)n_pics), dim3(256), 0, vs, dp, p->vgeom);
-    hipLaunchKernelGGL(leon::k_vlc_gather, dim3((unsigned)((n_slices + 3) / 4)), dim3(256), 0, vs, ds, d_words, (int)n_slices, dp, p->vgeom, p->d_vlc_tables);
+    hipLaunchKernelGGL(leon::k_vlc_blocks, dim3((unsigned)((n_slices + 3) / 4)), dim3(256), 0, vs, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(R.h_err, d_err, n_pics * 4, hipMemcpyDeviceToHost, vs));
     return LEON_OK;
@@ -963,6 +963,22 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
             const int len = (int)(f & 0x7f), run = (int)((f >> 8) & 0xff), level = (int)(int16_t)(f >> 16);
             if (len > 15 || run > 31 || level < -32 || level > 31) { leon_pipeline_destroy(p); return fail(LEON_ERR_INVALID, "coefficient table does not fit 16 bits"); }
             t[0].fast12[i] = (uint16_t)(len | ((f & 0x80u) ? 0x10 : 0) | (run << 5) | ((level & 63) << 10));
+        }
+        // multi12: every symbol that lies complete in the next 12 bits, taken together (a prefix code is decided by its own
+        // bits: the entry of the pattern shifted up, whatever follows, names the symbol if its length fits what is left)
+        for (int i = 0; i < 4096; i++) {
+            int pos = 0, nsym = 0, adv = 0, eob = 0;
+            while (pos < 12) {
+                const uint32_t f = src[0].fast12[(i << pos) & 0xfff];
+                const int len = (int)(f & 0x7f);
+                if (len == 0 || len > 12 - pos) break;
+                pos += len;
+                if (f & 0x80u) { eob = 1; break; }
+                nsym++;
+                adv += (int)((f >> 8) & 0xff) + 1;
+            }
+            if (nsym > 7 || adv > 255) { leon_pipeline_destroy(p); return fail(LEON_ERR_INVALID, "multi-symbol table does not fit 16 bits"); }
+            t[0].multi12[i] = (uint16_t)(pos | (nsym << 4) | (eob << 7) | (adv << 8));
         }
         auto pack = [](int32_t e) { return (uint16_t)(((e >> 16) << 8) | (e & 0xff)); };
         for (int i = 0; i < 2048; i++) { t[0].motion_s[i] = pack(src[0].motion_s[i]); t[0].mba[i] = pack(src[0].mba[i]); }

@@ -12,14 +12,19 @@
 // 128 GOPs x 12 pictures: ~100 000 independent slices, one LANE each.  16 host cores parse 14 k pictures/s;
 // the reconstruction kernels take 220 k/s.
 //
-//   k_vlc_parse    one lane per slice: macroblock maps straight into the picture's arrays; coefficients into the
-//                  slice's scratch strip -- one header word {group id, count} per coded block at its front, the
-//                  entries behind, both in decoding order -- and the count added to the group's counter.
+//   k_vlc_parse    one lane per slice, the SERIAL part only: macroblock headers and vectors (maps straight into the
+//                  picture's arrays), DC values, and for every coded block WHERE its coefficient symbols begin and how
+//                  many there are -- the symbols themselves are stepped over, several at a time (one table lookup on
+//                  12 bits gives the bits, the number of symbols and the positions they advance, up to the end of
+//                  block).  One 12-byte record per coded block into the slice's strip, its count added to the group's counter.
 //   k_vlc_offsets  one workgroup per picture: exclusive scan of the group counters -> grp_off (what
 //                  leon_sparse_picture wants), counters back to zero (they become cursors).
-//   k_vlc_gather   one WAVE per slice: 64 block headers at a time, a wave prefix sum of their counts finds each
-//                  block's entries, which move to grp_off[group] + cursor (atomic add of the block's count).
-//                  Entries of a group are "in no particular order" (include/leon_vlc.h).
+//   k_vlc_blocks   the PARALLEL part, one lane per coded block (a wave walks the records of one slice, 64 at a time):
+//                  decodes the block's symbols from its bit position and writes the entries to grp_off[group] + cursor
+//                  (atomic add of the block's count).  Entries of a group are "in no particular order" (include/leon_vlc.h).
+// Round 2 decoded the coefficients in the slice loop (one kernel + a gather): a launch lasted as long as its longest
+// slice, symbol after symbol, 170 ns each.  A block's end can only be found by reading its symbols' LENGTHS in order --
+// but nothing else of them is needed there.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -31,24 +36,32 @@ namespace leon {
 // stored a symbol earlier to reach memory.
 #define VLC_G __attribute__((address_space(1)))
 
-// Device copy of the front end's tables (leon_vlc_get_gpu_tables), the LDS part first and in 16 bits:
-//   fast12: bits 0..3 length (0 = longer code or escape), bit 4 end of block, bits 5..9 run, bits 10..15 level
-//   long9:  the codes of 12 .. 16 bits (all of them start with seven zeros) by the nine bits behind those zeros:
-//           bits 0..4 length without the sign bit, bits 5..9 run, bits 10..15 level (unsigned), 0 = invalid code
+// Device copy of the front end's tables (leon_vlc_get_gpu_tables), 16 bits per entry; k_vlc_parse's part first:
+//   multi12: the coefficient symbols that lie COMPLETE in the next 12 bits, stepped over together: bits 0..3 the bits
+//            they take (0 = the first one is a longer code or an escape), bits 4..6 how many symbols (the end-of-block
+//            code not counted), bit 7 an end-of-block code is among them (the last one), bits 8..15 the sum of (run + 1)
+//   long9:   the codes of 12 .. 16 bits (all of them start with seven zeros) by the nine bits behind those zeros:
+//            bits 0..4 length without the sign bit, bits 5..9 run, bits 10..15 level (unsigned), 0 = invalid code
+//   fast12:  one symbol from the next 12 bits (k_vlc_blocks): bits 0..3 length (0 = longer code or escape), bit 4 end of
+//            block, bits 5..9 run, bits 10..15 level
 //   the others: (length << 8) | value, 0 = invalid code
 struct VlcTables {
-    uint16_t fast12[4096];
+    uint16_t multi12[4096];
     uint16_t long9[512];
     uint16_t motion_s[2048];
     uint16_t mba[2048];
     uint16_t cbp[512];
     uint16_t mbtype[4][64];
     uint16_t dc_lum[128], dc_chr[256];
+    uint16_t fast12[4096];       // k_vlc_blocks
     uint16_t zz_off[64];
 };
-static constexpr int kVlcLdsWords = (4096 + 512 + 2048 + 2048 + 512 + 256 + 128 + 256 + 64) / 2;
+static constexpr int kVlcLdsWords = (4096 + 512 + 2048 + 2048 + 512 + 256 + 128 + 256) / 2;
 // every lane reads its slice through a ring of 16 dwords in LDS: dword i of lane L at ring[(i & 15) * 64 + L]
 static constexpr int kVlcRingDwords = 16;
+// a coded block as k_vlc_parse hands it to k_vlc_blocks: {bit position of its first coefficient symbol (behind the DC of an
+// intra block), group | block of the group << 20 | intra << 23 | entries << 24, DC level | has one << 16}
+static constexpr int kVlcRecWords = 3;
 static constexpr int kVlcRingBytesPerWave = kVlcRingDwords * 64 * 4;
 
 struct VlcGeom {
@@ -74,9 +87,9 @@ struct VlcSlice {
     uint32_t end_byte;           // first byte behind the slice
     int32_t code;                // slice_vertical_position
     uint32_t pic;
-    uint32_t hdr_cap;            // block headers the strip has room for ...
-    uint32_t ent_cap;            // ... and entries behind them
-    uint32_t* scratch;           // [hdr_cap headers][ent_cap entries]
+    uint32_t hdr_cap;            // block records the strip has room for
+    uint32_t ent_cap;            // (unused since round 3: the entries go straight to the picture's lists)
+    uint32_t* scratch;           // [hdr_cap records of kVlcRecWords dwords]
 };
 
 enum { VLC_ERR_MBA = 1, VLC_ERR_ADDR, VLC_ERR_TYPE, VLC_ERR_MOTION, VLC_ERR_CBP, VLC_ERR_COEF, VLC_ERR_INDEX, VLC_ERR_END, VLC_ERR_DC,
@@ -178,14 +191,13 @@ struct VlcWin {
 };
 
 struct VlcLds {
-    uint16_t fast12[4096];
+    uint16_t multi12[4096];
     uint16_t long9[512];
     uint16_t motion_s[2048];
     uint16_t mba[2048];
     uint16_t cbp[512];
     uint16_t mbtype[4][64];
     uint16_t dc_lum[128], dc_chr[256];
-    uint16_t zz_off[64];
 };
 static_assert(sizeof(VlcLds) == kVlcLdsWords * 4, "LDS copy and VlcTables disagree");
 
@@ -194,10 +206,8 @@ struct VlcCtx {                  // per lane: the state a slice carries from mac
     int fw_h, fw_v, fw_h_prev, fw_v_prev, bw_h, bw_v, bw_h_prev, bw_v_prev, prev_dir;
     int dc_y, dc_cr, dc_cb, dc_a, qs;
     int mb_intra;
-    VLC_G uint32_t* hdr;         // next free block header of the scratch strip
-    VLC_G uint32_t* ent;         // next free entry
+    VLC_G uint32_t* hdr;         // next free block record of the slice's strip
     VLC_G uint32_t* hdr_end;
-    VLC_G uint32_t* ent_end;
     VLC_G char* zbase;           // the picture's counters and maps
     int type, full_pel_fwd, fwd_rsize, full_pel_bwd, bwd_rsize;
     uint32_t* wave_ring;         // LDS ring of the wave (VlcWin::sync)
@@ -225,15 +235,16 @@ __device__ __forceinline__ int vlc_motion_component(VlcWin& r, const VlcLds& L, 
     return prev;
 }
 
-// decoders/jsv.js:1338-1525 (decodeBlockGL), as decode_block of leon_vlc.cpp; returns an error code or 0
-// (All coded blocks of a macroblock in ONE loop -- an iteration = one symbol of whatever block the lane is in -- was
-// tried twice, the second time with a block start of a dozen instructions, and is slower both times: 71 k against
-// 93-95 k pictures/s end to end on one box.  The tight per-slot loop wins although it runs more iterations.)
+// decoders/jsv.js:1338-1525 (decodeBlockGL), the serial half: the DC value, then the block's coefficient symbols are
+// STEPPED OVER -- their lengths decide where the block ends, nothing else of them is needed here (k_vlc_blocks reads them
+// again, a lane per block).  One lookup on the next 12 bits covers every symbol that lies complete in them: the bits they
+// take, how many they are, the positions they advance, and whether the last one is the end-of-block code.  Same error
+// conditions as decode_block of leon_vlc.cpp: an invalid code, a position past 63, the end of the data.
 // COMP (which DC predictor, which DC table): 0 luma blocks 0..3, 1 block 4, 2 block 5, 3 the A blocks 6..9 -- a template
 // parameter: chosen at run time, the predictor would be read through a computed address and the whole context
 // would live in scratch memory
 template <int COMP>
-__device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTables* __restrict__ T, const VlcGeom& G, VlcCtx& c, int block)
+__device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcGeom& G, VlcCtx& c, int block)
 {
     uint32_t gid, bq;
     if (COMP == 0 || COMP == 3) {                            // luma, or the A component (blocks 6..9, placed like luma)
@@ -245,12 +256,9 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
         gid = (uint32_t)(G.n_y + (COMP == 2 ? G.n_c : 0) + c.mb_row * G.gc + (c.mb_col >> 3));
         bq = (uint32_t)(c.mb_col & 7);
     }
-    // an entry as k_vlc_parse leaves it: (block of the group * 64 + zig-zag index) << 16 | level; k_vlc_gather turns the
-    // index into the tile offset of include/leon_vlc.h on its way (the table lookup was an LDS round trip per symbol here)
-    const uint32_t bbase = (bq * 64u) << 16;
-    if (c.hdr >= c.hdr_end || c.ent + 64 > c.ent_end) return VLC_ERR_SCRATCH;      // a block: one header, at most 64 entries
-    VLC_G uint32_t* const rec = c.ent;
+    if (c.hdr + kVlcRecWords > c.hdr_end) return VLC_ERR_SCRATCH;
     int k = 0, n = 0;
+    uint32_t dcw = 0u;
     if (c.mb_intra) {
         VLC_SYNC(r, c);
         r.fill();
@@ -267,67 +275,57 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcTa
                                                     : predictor + ((int)(0xffffffffu << size) | (differential + 1));
         }
         if (COMP == 0) c.dc_y = dc; else if (COMP == 3) c.dc_a = dc; else if (COMP == 1) c.dc_cr = dc; else c.dc_cb = dc;
-        if ((int16_t)dc != 0) rec[k++] = bbase | (uint16_t)(int16_t)dc;
+        if ((int16_t)dc != 0) { dcw = 0x10000u | (uint32_t)(uint16_t)(int16_t)dc; k = 1; }
         n = 1;
     }
+    const uint32_t start = r.pos;                            // the block's coefficient symbols begin here
     // the first symbol of a non-intra block: '1s' is run 0, level +-1 (two bits), and there is no end-of-block code.
-    // Every other first symbol starts with a 0 bit and reads like any later one: only this case is handled here, in
-    // front of the loop (inside it, the test cost every iteration six instructions).
+    // Every other first symbol starts with a 0 bit and reads like any later one.
     if (n == 0) {
         VLC_SYNC(r, c);
         r.fill();
-        const uint32_t p2 = r.peek(2);
-        if (p2 & 2u) {
-            r.drop(2);
-            rec[k++] = bbase | (uint32_t)(uint16_t)(int16_t)((p2 & 1u) ? -1 : 1);      // zig-zag position 0
-            n = 1;
-        }
+        if (r.peek(2) & 2u) { r.drop(2); k = 1; n = 1; }
     }
     for (;;) {
         VLC_SYNC(r, c);
         r.fill();
-        const uint32_t f = L.fast12[(uint32_t)(r.w >> 52)];
-        const int flen = (int)(f & 0xfu);
-        int run_len, level;
-        if (flen) {
-            r.drop(flen);
-            if (f & 0x10u) break;                             // end of block
-            run_len = (int)((f >> 5) & 31u);
-            level = (int)(int16_t)(uint16_t)f >> 10;
+        const uint32_t m = L.multi12[(uint32_t)(r.w >> 52)];
+        const int used = (int)(m & 15u);
+        if (used) {
+            r.drop(used);
+            k += (int)((m >> 4) & 7u);
+            n += (int)(m >> 8);                              // every symbol: its run, and the position it fills
+            if (n > 64) return VLC_ERR_INDEX;                // = the last symbol's position past 63 (the earlier ones lie below it)
+            if (m & 0x80u) break;                            // end of block
         } else {
-            // escapes ('0000 01', read arithmetically) and the codes of 12 .. 16 bits (seven zeros in front; a second
-            // table in LDS).  (Through the 16-bit table in global memory, a wave waited for memory in one iteration
-            // of six: some lane of the 64 is here.)
+            // one symbol: an escape ('0000 01', 20 or 28 bits) or a code of 12 .. 16 bits (seven zeros in front; a
+            // second table in LDS)
             const uint64_t w = r.w;
-            int used;
-            if ((w >> 58) == 1u) {                           // escape: 6-bit run, 8- or 16-bit level
+            int used1, run_len;
+            if ((w >> 58) == 1u) {
                 run_len = (int)((w >> 52) & 63);
-                level = (int)((w >> 44) & 255);
-                used = 20;
-                if (level == 0) { level = (int)((w >> 36) & 255); used = 28; }
-                else if (level == 128) { level = (int)((w >> 36) & 255) - 256; used = 28; }
-                else if (level > 128) level -= 256;
+                const uint32_t l8 = (uint32_t)(w >> 44) & 255u;
+                used1 = (l8 == 0u || l8 == 128u) ? 28 : 20;
             } else {
                 if ((w >> 57) != 0u) return VLC_ERR_COEF;
                 const uint32_t e = L.long9[(uint32_t)(w >> 48) & 511u];
                 if (e == 0u) return VLC_ERR_COEF;
-                const int len = (int)(e & 31u);
                 run_len = (int)((e >> 5) & 31u);
-                level = (int)(e >> 10);
-                if ((w >> (63 - len)) & 1) level = -level;
-                used = len + 1;
+                used1 = (int)(e & 31u) + 1;
             }
-            r.drop(used);
+            r.drop(used1);
+            n += run_len;
+            if (n > 63) return VLC_ERR_INDEX;
+            n++;
+            k++;
         }
-        n += run_len;
-        if (n > 63) return VLC_ERR_INDEX;
-        if (level != 0) rec[k++] = bbase | ((uint32_t)n << 16) | (uint16_t)(int16_t)level;
-        n++;
     }
     if (r.pos > (uint32_t)(r.nd << 5)) return VLC_ERR_END;     // ran off the data (zeros behind it: an invalid code ended the loop at the latest)
     if (k) {
-        *c.hdr++ = (gid << 7) | (uint32_t)k;
-        c.ent = rec + k;
+        c.hdr[0] = start;
+        c.hdr[1] = gid | (bq << 20) | (c.mb_intra ? 1u << 23 : 0u) | ((uint32_t)k << 24);
+        c.hdr[2] = dcw;
+        c.hdr += kVlcRecWords;
         __hip_atomic_fetch_add(reinterpret_cast<VLC_G uint32_t*>(c.zbase + G.off_cnt) + gid, (uint32_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return 0;
@@ -348,7 +346,7 @@ __device__ __forceinline__ int vlc_mba(VlcWin& r, const VlcLds& L, VlcCtx& c)
 
 // decoders/jsv.js:725-828 (+ B pictures), as decode_macroblock of leon_vlc.cpp.  0 = macroblock read, 1 = stop
 // silently (an address past the picture), > 1 an error
-__device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const VlcTables* __restrict__ T, const VlcGeom& G, VlcCtx& c,
+__device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const VlcGeom& G, VlcCtx& c,
                                               bool& slice_begin)
 {
     const int type = c.type, mbsize = G.mbw * G.mbh;
@@ -449,12 +447,12 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
     if (G.alpha) apat = c.mb_intra ? 0xf : (int)r.get(4);     // pattern (<= 9 bits) and alpha_pattern: one dword at most
 #pragma unroll 1
     for (int block = 0, mask = 0x20; block < 4; block++, mask >>= 1)
-        if (cbp & mask) { const int e = vlc_block<0>(r, L, T, G, c, block); if (e) return e + 1; }
-    if (cbp & 0x2) { const int e = vlc_block<1>(r, L, T, G, c, 4); if (e) return e + 1; }
-    if (cbp & 0x1) { const int e = vlc_block<2>(r, L, T, G, c, 5); if (e) return e + 1; }
+        if (cbp & mask) { const int e = vlc_block<0>(r, L, G, c, block); if (e) return e + 1; }
+    if (cbp & 0x2) { const int e = vlc_block<1>(r, L, G, c, 4); if (e) return e + 1; }
+    if (cbp & 0x1) { const int e = vlc_block<2>(r, L, G, c, 5); if (e) return e + 1; }
 #pragma unroll 1
     for (int block = 6, mask = 0x8; block < 10; block++, mask >>= 1)
-        if (apat & mask) { const int e = vlc_block<3>(r, L, T, G, c, block); if (e) return e + 1; }
+        if (apat & mask) { const int e = vlc_block<3>(r, L, G, c, block); if (e) return e + 1; }
     return 0;
 }
 
@@ -492,8 +490,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     c.rc_addr = c.mb_addr;
     c.dc_y = c.dc_cr = c.dc_cb = c.dc_a = 128;
     c.hdr = (VLC_G uint32_t*)S.scratch;
-    c.hdr_end = c.ent = c.hdr + S.hdr_cap;
-    c.ent_end = c.ent + S.ent_cap;
+    c.hdr_end = c.hdr + S.hdr_cap * kVlcRecWords;
     c.qs = (int)r.get(5);
     for (;;) {                                                // extra_information_slice
         VLC_SYNC(r, c);
@@ -503,7 +500,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
     bool slice_begin = true;
     int err = 0;
     for (;;) {
-        const int rc = vlc_macroblock(r, L, T, G, c, slice_begin);       // 1: the reference's silent return, the loop goes on
+        const int rc = vlc_macroblock(r, L, G, c, slice_begin);       // 1: the reference's silent return, the loop goes on
         if (rc > 1) { err = rc - 1; break; }
         // next_bits_are_start_code (decoders/jsv.js:1710-1760): byte aligned 00 00 01, or the end of the data
         VLC_SYNC(r, c);
@@ -513,7 +510,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) voi
         if ((uint32_t)((r.w << skip) >> 40) == 1u) break;
         if (i >= S.end_byte) { err = VLC_ERR_END; break; }    // behind the start code the host found: ran over it
     }
-    ((VLC_G uint32_t*)slice_words)[j] = (uint32_t)(c.hdr - (VLC_G uint32_t*)S.scratch);       // coded blocks of the slice
+    ((VLC_G uint32_t*)slice_words)[j] = (uint32_t)(c.hdr - (VLC_G uint32_t*)S.scratch) / kVlcRecWords;       // coded blocks of the slice
     if (err) atomicCAS(errors + S.pic, 0u, (uint32_t)err | ((uint32_t)S.code << 8));     // rare: a generic atomic is fine here
 }
 
@@ -526,7 +523,7 @@ __global__ __launch_bounds__(256) void k_vlc_clear(const VlcClear* __restrict__ 
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < R.n16; i += (uint64_t)gridDim.x * 256) R.ptr[i] = uint4{0u, 0u, 0u, 0u};
 }
 
-// exclusive scan of a picture's group counters; the counters go back to zero (k_vlc_gather's cursors)
+// exclusive scan of a picture's group counters; the counters go back to zero (k_vlc_blocks' cursors)
 __global__ __launch_bounds__(256) void k_vlc_offsets(const VlcPic* __restrict__ pics, VlcGeom G)
 {
     __shared__ uint32_t part[256];
@@ -554,11 +551,18 @@ __global__ __launch_bounds__(256) void k_vlc_offsets(const VlcPic* __restrict__ 
     if (threadIdx.x == 255) P.grp_off[ng] = part[255];
 }
 
-__global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__ slices, const uint32_t* __restrict__ slice_blocks, int n_slices,
-                                                    const VlcPic* __restrict__ pics, VlcGeom G, const VlcTables* __restrict__ T)
+// The parallel half: the symbols of every coded block, a lane per block.  One WAVE per slice walks the slice's records 64
+// at a time; a lane reads its block's bits straight from memory (three dwords cover most blocks), decodes run / level
+// pairs until the end-of-block code and writes them as entries (tile offset << 16 | level) to grp_off[group] + cursor.
+// Same symbol reading as leon_vlc.cpp's decode_block; a block that does not read the way k_vlc_parse counted it (it
+// cannot, both read the same bits with the same tables) sets the picture's error word instead of leaving entries undefined.
+__global__ __launch_bounds__(256) void k_vlc_blocks(const VlcSlice* __restrict__ slices, const uint32_t* __restrict__ slice_blocks, int n_slices,
+                                                    const VlcPic* __restrict__ pics, uint32_t* __restrict__ errors, VlcGeom G,
+                                                    const VlcTables* __restrict__ T)
 {
-    __shared__ uint32_t s_from[4][65], s_at[4][64];                  // per wave: where the round's blocks start in the strip, where they go
-    __shared__ uint16_t s_zz[64];                                    // zig-zag index -> byte offset of the coefficient in its block's part of the tile
+    __shared__ uint16_t s_fast[4096], s_long[512], s_zz[64];
+    for (int i = threadIdx.x; i < 4096; i += 256) s_fast[i] = T->fast12[i];
+    for (int i = threadIdx.x; i < 512; i += 256) s_long[i] = T->long9[i];
     if (threadIdx.x < 64) s_zz[threadIdx.x] = T->zz_off[threadIdx.x];
     __syncthreads();
     const int wv = (int)(threadIdx.x >> 6);
@@ -569,64 +573,80 @@ __global__ __launch_bounds__(256) void k_vlc_gather(const VlcSlice* __restrict__
     const VlcPic P = pics[S.pic];
     VLC_G uint32_t* const cursor = reinterpret_cast<VLC_G uint32_t*>((VLC_G char*)P.zbase + G.off_cnt);
     const uint32_t n_blocks = min(slice_blocks[j], S.hdr_cap);
-    const VLC_G uint32_t* const hdr = (const VLC_G uint32_t*)S.scratch;
-    const VLC_G uint32_t* const ent = hdr + S.hdr_cap;
+    const VLC_G uint32_t* const rec = (const VLC_G uint32_t*)S.scratch;
+    const VLC_G uint32_t* const bytes = (const VLC_G uint32_t*)S.bytes;
     const VLC_G uint32_t* const grp_off = (const VLC_G uint32_t*)P.grp_off;
     VLC_G uint32_t* const entries = (VLC_G uint32_t*)P.entries;
-    uint32_t carry = 0;                                              // entries of the blocks before this round
+    uint32_t err = 0;
     for (uint32_t base = 0; base < n_blocks; base += 64) {
         const uint32_t b = base + (uint32_t)lane;
-        const uint32_t h = b < n_blocks ? hdr[b] : 0u;
-        const uint32_t gid = h >> 7, k = h & 127u;
-        uint32_t incl = k;                                           // inclusive prefix sum of k over the wave
-#pragma unroll
-        for (int d = 1; d < 64; d <<= 1) {
-            const uint32_t up = (uint32_t)__shfl_up((int)incl, d, 64);
-            if (lane >= d) incl += up;
+        if (b >= n_blocks) continue;
+        const uint32_t bit = rec[b * kVlcRecWords], r1 = rec[b * kVlcRecWords + 1], dcw = rec[b * kVlcRecWords + 2];
+        const uint32_t gid = r1 & 0xfffffu, bq = (r1 >> 20) & 7u, k = r1 >> 24;
+        const bool intra = (r1 >> 23) & 1u;
+        if (k == 0u || k > 64u) continue;
+        const uint32_t at = grp_off[gid] + __hip_atomic_fetch_add(cursor + gid, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (at + k > P.entries_cap) { err = VLC_ERR_SCRATCH; continue; }
+        VLC_G uint32_t* out = entries + at;
+        const uint32_t bbase = (bq * 16u) << 16;
+        // the lane's window: 64 bits from `bit` on, refilled a dword at a time
+        uint32_t next = bit >> 5;
+        auto dword = [&](uint32_t i) -> uint32_t { return i < S.n_dwords ? __builtin_bswap32(bytes[i]) : 0u; };
+        const uint32_t lead = bit & 31u;
+        uint64_t w = (((uint64_t)dword(next) << 32) | dword(next + 1u)) << lead;
+        int avail = 64 - (int)lead;
+        next += 2u;
+        uint32_t written = 0u;
+        int n = 0;
+        if (intra) {
+            if (dcw & 0x10000u) out[written++] = bbase | (dcw & 0xffffu);
+            n = 1;
+        } else if ((uint32_t)(w >> 62) & 2u) {                       // '1s': run 0, level +-1 in first position
+            out[written++] = bbase | (uint32_t)(uint16_t)(int16_t)(((uint32_t)(w >> 62) & 1u) ? -1 : 1);
+            w <<= 2; avail -= 2;
+            n = 1;
         }
-        const uint32_t from = carry + incl - k;
-        const uint32_t round_begin = carry;
-        carry += (uint32_t)__shfl((int)incl, 63, 64);
-        // Neighbouring lanes often hold the two blocks of one macroblock that lie in the same group (Y0 Y1, Y2 Y3):
-        // such a pair takes ONE atomic add -- the launch is bound by their rate.  A lane follows its left neighbour
-        // when both have entries for the same group and the neighbour does not follow somebody itself.
-        const uint32_t gid_l = (uint32_t)__shfl_up((int)gid, 1, 64), k_l = (uint32_t)__shfl_up((int)k, 1, 64);
-        const bool same_l = lane > 0 && k != 0u && k_l != 0u && gid_l == gid;
-        const bool follows = same_l && !__shfl_up((int)same_l, 1, 64);
-        const bool followed = __shfl_down((int)follows, 1, 64) != 0 && lane < 63;
-        const uint32_t k_r = (uint32_t)__shfl_down((int)k, 1, 64);
-        const bool ok = k != 0u && k <= 64u && from + k <= S.ent_cap;
-        uint32_t at = 0u;
-        if (ok && !follows) at = grp_off[gid] + __hip_atomic_fetch_add(cursor + gid, followed ? k + k_r : k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const uint32_t at_l = (uint32_t)__shfl_up((int)at, 1, 64);
-        if (follows) at = at_l + k_l;
-        // The entries of the round's blocks lie one behind the other in the strip: the wave copies them 64 at a time,
-        // contiguous reads, each lane finding the block its entry belongs to by a binary search over the blocks' start
-        // offsets (in LDS).  A lane copying its own block entry by entry issued as many instructions as the longest
-        // block of the wave is long, each with 64 addresses 4 bytes wide all over memory.
-        s_from[wv][lane] = from;
-        s_at[wv][lane] = ok && at + k <= P.entries_cap ? at : 0xffffffffu;
-        if (lane == 63) s_from[wv][64] = carry;
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const uint32_t round_end = min(carry, S.ent_cap);
-        for (uint32_t e = round_begin + (uint32_t)lane; e < round_end; e += 64u) {
-            uint32_t lo = 0;
-#pragma unroll
-            for (uint32_t step = 32; step != 0; step >>= 1)
-                if (s_from[wv][lo + step] <= e) lo += step;
-            const uint32_t dst = s_at[wv][lo];
-            if (dst != 0xffffffffu) {
-                // (block * 64 + zig-zag index) -> the tile offset block * 16 + zz_off[index]
-                const uint32_t v = ent[e], hi = v >> 16;
-                entries[dst + (e - s_from[wv][lo])] = ((((hi >> 6) & 7u) * 16u + s_zz[hi & 63u]) << 16) | (v & 0xffffu);
+        bool ok = false;
+        for (int it = 0; it < 66; it++) {
+            if (avail <= 32) { w |= (uint64_t)dword(next++) << (32 - avail); avail += 32; }
+            const uint32_t f = s_fast[(uint32_t)(w >> 52)];
+            const int flen = (int)(f & 0xfu);
+            int run_len, level, used;
+            if (flen) {
+                if (f & 0x10u) { ok = true; break; }                 // end of block
+                used = flen;
+                run_len = (int)((f >> 5) & 31u);
+                level = (int)(int16_t)(uint16_t)f >> 10;
+            } else if ((w >> 58) == 1u) {                            // escape: 6-bit run, 8- or 16-bit level
+                run_len = (int)((w >> 52) & 63);
+                level = (int)((w >> 44) & 255);
+                used = 20;
+                if (level == 0) { level = (int)((w >> 36) & 255); used = 28; }
+                else if (level == 128) { level = (int)((w >> 36) & 255) - 256; used = 28; }
+                else if (level > 128) level -= 256;
+            } else {
+                const uint32_t e = (w >> 57) == 0u ? s_long[(uint32_t)(w >> 48) & 511u] : 0u;
+                if (e == 0u) break;
+                const int len = (int)(e & 31u);
+                run_len = (int)((e >> 5) & 31u);
+                level = (int)(e >> 10);
+                if ((w >> (63 - len)) & 1) level = -level;
+                used = len + 1;
             }
+            w <<= used; avail -= used;
+            n += run_len;
+            if (n > 63 || written >= k) break;
+            // (a level of 0 -- an escape that codes nothing -- is written too: k_vlc_parse counted the symbol, and an entry
+            // with level 0 puts a zero where zero is)
+            out[written++] = bbase | ((uint32_t)s_zz[n] << 16) | (uint32_t)(uint16_t)(int16_t)level;
+            n++;
         }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!ok || written != k) {
+            err = VLC_ERR_COEF;
+            for (; written < k; written++) out[written] = 0u;        // nothing undefined in the lists
+        }
     }
+    if (err) atomicCAS(errors + S.pic, 0u, err | ((uint32_t)S.code << 8));
 }
 
 }  // namespace leon
