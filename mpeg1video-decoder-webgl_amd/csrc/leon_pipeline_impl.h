@@ -966,18 +966,20 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
         }
         // multi12: every symbol that lies complete in the next 12 bits, taken together (a prefix code is decided by its own
         // bits: the entry of the pattern shifted up, whatever follows, names the symbol if its length fits what is left)
-        for (int i = 0; i < 4096; i++) {
+        for (int i = 0; i < leon::kVlcMulti; i++) {
+            const int B = leon::kVlcMultiBits;
             int pos = 0, nsym = 0, adv = 0, eob = 0;
-            while (pos < 12) {
-                const uint32_t f = src[0].fast12[(i << pos) & 0xfff];
+            while (pos < B) {
+                // the 12 bits from `pos` on, zeros behind the pattern's end
+                const uint32_t f = src[0].fast12[(((uint32_t)i << pos) & (uint32_t)(leon::kVlcMulti - 1)) << 12 >> B];
                 const int len = (int)(f & 0x7f);
-                if (len == 0 || len > 12 - pos) break;
+                if (len == 0 || len > B - pos) break;
                 pos += len;
                 if (f & 0x80u) { eob = 1; break; }
                 nsym++;
                 adv += (int)((f >> 8) & 0xff) + 1;
             }
-            if (nsym > 7 || adv > 255) { leon_pipeline_destroy(p); return fail(LEON_ERR_INVALID, "multi-symbol table does not fit 16 bits"); }
+            if (pos > 15 || nsym > 7 || adv > 255) { leon_pipeline_destroy(p); return fail(LEON_ERR_INVALID, "multi-symbol table does not fit 16 bits"); }
             t[0].multi12[i] = (uint16_t)(pos | (nsym << 4) | (eob << 7) | (adv << 8));
         }
         auto pack = [](int32_t e) { return (uint16_t)(((e >> 16) << 8) | (e & 0xff)); };

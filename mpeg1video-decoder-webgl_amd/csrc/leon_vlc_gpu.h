@@ -36,6 +36,12 @@ namespace leon {
 // stored a symbol earlier to reach memory.
 #define VLC_G __attribute__((address_space(1)))
 
+#ifndef LEON_VLC_MULTI_BITS
+#define LEON_VLC_MULTI_BITS 12
+#endif
+static constexpr int kVlcMultiBits = LEON_VLC_MULTI_BITS;      // how many bits of the stream one step of k_vlc_parse's coefficient loop looks at
+static constexpr int kVlcMulti = 1 << kVlcMultiBits;
+
 // Device copy of the front end's tables (leon_vlc_get_gpu_tables), 16 bits per entry; k_vlc_parse's part first:
 //   multi12: the coefficient symbols that lie COMPLETE in the next 12 bits, stepped over together: bits 0..3 the bits
 //            they take (0 = the first one is a longer code or an escape), bits 4..6 how many symbols (the end-of-block
@@ -46,7 +52,7 @@ namespace leon {
 //            block, bits 5..9 run, bits 10..15 level
 //   the others: (length << 8) | value, 0 = invalid code
 struct VlcTables {
-    uint16_t multi12[4096];
+    uint16_t multi12[kVlcMulti];
     uint16_t long9[512];
     uint16_t motion_s[2048];
     uint16_t mba[2048];
@@ -56,7 +62,7 @@ struct VlcTables {
     uint16_t fast12[4096];       // k_vlc_blocks
     uint16_t zz_off[64];
 };
-static constexpr int kVlcLdsWords = (4096 + 512 + 2048 + 2048 + 512 + 256 + 128 + 256) / 2;
+static constexpr int kVlcLdsWords = (kVlcMulti + 512 + 2048 + 2048 + 512 + 256 + 128 + 256) / 2;
 // every lane reads its slice through a ring of 16 dwords in LDS: dword i of lane L at ring[(i & 15) * 64 + L]
 static constexpr int kVlcRingDwords = 16;
 // a coded block as k_vlc_parse hands it to k_vlc_blocks: {bit position of its first coefficient symbol (behind the DC of an
@@ -191,7 +197,7 @@ struct VlcWin {
 };
 
 struct VlcLds {
-    uint16_t multi12[4096];
+    uint16_t multi12[kVlcMulti];
     uint16_t long9[512];
     uint16_t motion_s[2048];
     uint16_t mba[2048];
@@ -289,7 +295,7 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcGe
     for (;;) {
         VLC_SYNC(r, c);
         r.fill();
-        const uint32_t m = L.multi12[(uint32_t)(r.w >> 52)];
+        const uint32_t m = L.multi12[(uint32_t)(r.w >> (64 - kVlcMultiBits))];
         const int used = (int)(m & 15u);
         if (used) {
             r.drop(used);

@@ -3,9 +3,9 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=${1:-gpurun_out/sq_vlc}
 mkdir -p $out
-S="python3 tools/pipeline_bench.py --loop 768 --threads 16 --window 256 --gpu-parser"
+S="python3 tools/pipeline_bench.py --varied --loop 96 --threads 16 --window 128 --inflight 3 --gpu-parser"
 i=0
-for c in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
+for c in "SQ_THREAD_CYCLES_VALU SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" "SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_SMEM" \
          "SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM" "SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_BUSY_CYCLES" \
          "SQ_WAIT_INST_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_SCA"; do
   i=$((i+1)); timeout -k 10 200 rocprofv3 --pmc $c -d $out/p$i --output-format csv -- $S > $out/p$i.log 2>&1 || echo "pass $i ($c) failed"
@@ -26,6 +26,9 @@ for k in sorted(pmc):
     w=pmc[k].get("SQ_WAVES",1)
     print(k, "waves", w)
     print('   ', {c:round(v/w,1) for c,v in sorted(pmc[k].items())})
+    if "SQ_THREAD_CYCLES_VALU" in pmc[k] and pmc[k].get("SQ_ACTIVE_INST_VALU"):
+        # thread-cycles over instruction-cycles = lanes that were active, on average, when a vector instruction executed
+        print('    active lanes per vector instruction: %.1f of 64' % (pmc[k]["SQ_THREAD_CYCLES_VALU"] / pmc[k]["SQ_ACTIVE_INST_VALU"]))
 PY
 rm -rf $out
 echo done
