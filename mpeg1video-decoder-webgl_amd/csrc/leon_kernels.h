@@ -38,6 +38,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#ifndef LEON_CARRY
+#define LEON_CARRY 1
+#endif
 #ifndef LEON_PAIR_B
 #define LEON_PAIR_B 1
 #endif
@@ -645,8 +648,14 @@ __device__ __forceinline__ void display_half(const PicDesc& pd, const Geom& G, c
 // `alpha` (wave-uniform, luma-shaped tasks only): the task reconstructs the A plane of a yuva picture --
 // the same code path as luma with its own coefficient plane, the plane behind Cr in every slot, and the
 // alpha groups of the sparse lists.
-template <int TYPE, bool CHROMA, bool SPARSE, bool DISPLAY, int AMODE = 0>
-__device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int Rt, int g, char* lds, int lane, Display dsp, bool alpha = false)
+// CARRY (display tasks): the eight macroblocks of a task are looked up in the maps ONCE, by its chroma part (1: lane
+// (., m) loads macroblock m's quantiser scale, flags and vectors as always and leaves them in `carry`); the luma and
+// alpha parts (2) take theirs from the lane of their macroblock by ds_bpermute -- no loads, no second wait for memory
+// in front of their reference fetches.  0: a task on its own loads what it needs.
+struct MbCarry { uint32_t mf, mk, flags; };       // raw vector words; q | intra << 8 | repadd >= 128 << 9 | direction << 10
+
+template <int TYPE, bool CHROMA, bool SPARSE, bool DISPLAY, int AMODE = 0, int CARRY = 0>
+__device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int Rt, int g, char* lds, int lane, Display dsp, MbCarry& carry, bool alpha = false)
 {
     const int W = CHROMA ? G.cw >> 1 : G.cw;
     const int H = CHROMA ? G.ch >> 1 : G.ch;
@@ -700,20 +709,36 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
         coef_rows_to_lds(pd.coef[CHROMA ? 2 : (alpha ? 3 : 0)], lds + kLdsHalf, coef_voff, 2u * half_step);
     }
     const uint32_t mb = (uint32_t)(CHROMA ? Rt * G.mbw + Qs : Rt * G.mbw + (Qs >> 1));
-    const int q = ldg<uint8_t>(gptr(pd.qscale), mb) & 31;
-    const bool ia = ldg<uint8_t>(gptr(pd.intra), mb) != 0;   // I pictures honour the map too (COL_3)
+    uint32_t mf = 0, mk = 0, flags;
+    if constexpr (CARRY == 2) {
+        // this lane's macroblock is number 4 * side + (block >> 1) of the task: its chroma-part lane holds it
+        const int src = (4 * dsp.side + (lo3 >> 1)) << 2;
+        flags = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)carry.flags);
+        if (TYPE != 1) mf = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)carry.mf);
+        if (TYPE == 3) mk = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)carry.mk);
+    } else {
+        flags = (uint32_t)(ldg<uint8_t>(gptr(pd.qscale), mb) & 31) | (ldg<uint8_t>(gptr(pd.intra), mb) != 0 ? 256u : 0u);   // I pictures honour the intra map too (COL_3)
+        if (TYPE != 1) {
+            flags |= ldg<uint8_t>(gptr(pd.repadd), mb) >= 128 ? 512u : 0u;    // .r > 0.5
+            mf = ldg<uint32_t>(gptr(pd.mv_fwd), mb * 4);
+        }
+        if (TYPE == 3) {
+            mk = ldg<uint32_t>(gptr(pd.mv_bwd), mb * 4);
+            flags |= (uint32_t)(ldg<uint8_t>(gptr(pd.mb_dir), mb) & 3) << 10;
+        }
+        if constexpr (CARRY == 1) carry = MbCarry{mf, mk, flags};
+    }
+    const int q = (int)(flags & 31u);
+    const bool ia = (flags & 256u) != 0u;
     const int x0 = 8 * Qs;
     bool nopred = false;
     // per reference: window column, half-pel flags, vertical offset, base selection
     int pxA = 0, ayA = 0, ohA = 0, ovA = 0, pxB = 0, ayB = 0, ohB = 0, ovB = 0;
     bool inA = true, inB = true, usef = true, useb = true;
     if (TYPE != 1) {
-        nopred = ldg<uint8_t>(gptr(pd.repadd), mb) >= 128;    // .r > 0.5
-        uint32_t mf = ldg<uint32_t>(gptr(pd.mv_fwd), mb * 4);
-        uint32_t mk = 0;
+        nopred = (flags & 512u) != 0u;
         if (TYPE == 3) {
-            mk = ldg<uint32_t>(gptr(pd.mv_bwd), mb * 4);
-            const int dir = ldg<uint8_t>(gptr(pd.mb_dir), mb) & 3;
+            const int dir = (int)(flags >> 10) & 3;
             usef = (dir & 1) != 0;
             useb = (dir & 2) != 0;
             nopred = nopred || dir == 0;
@@ -1024,17 +1049,18 @@ template <int TYPE, bool SPARSE>
 __device__ __forceinline__ void recon_dispatch(const PicDesc& pd, const Geom& G, int t, char* lds, int lane)
 {
     const Display none{nullptr, 0};
+    MbCarry own{};
     if (t < G.tasksY) {
         int Rt = div_inv(t, G.inv_gY), g = t - Rt * G.gY;
-        recon_task<TYPE, false, SPARSE, false>(pd, G, Rt, g, lds, lane, none);
+        recon_task<TYPE, false, SPARSE, false>(pd, G, Rt, g, lds, lane, none, own);
     } else if (t < G.tasksY + G.tasksC) {
         t -= G.tasksY;
         int Rt = div_inv(t, G.inv_gC), g = t - Rt * G.gC;
-        recon_task<TYPE, true, SPARSE, false>(pd, G, Rt, g, lds, lane, none);
+        recon_task<TYPE, true, SPARSE, false>(pd, G, Rt, g, lds, lane, none, own);
     } else {                                   // yuva: the A plane, luma-shaped
         t -= G.tasksY + G.tasksC;
         int Rt = div_inv(t, G.inv_gY), g = t - Rt * G.gY;
-        recon_task<TYPE, false, SPARSE, false>(pd, G, Rt, g, lds, lane, none, true);
+        recon_task<TYPE, false, SPARSE, false>(pd, G, Rt, g, lds, lane, none, own, true);
     }
 }
 
@@ -1064,7 +1090,7 @@ __global__ __launch_bounds__(kReconMaxThreads) void k_recon(const PicDesc* __res
 // The sparse B kernel (what the pipeline runs most) is held to 72 registers = 7 waves per SIMD: it wants 74, the two
 // spilled dwords (8 bytes of scratch per lane) cost less than the wave brings: +1..2 % end to end, three pairs on one box.
 template <int TYPE, bool SPARSE, bool ALPHA = false>
-__global__ __launch_bounds__(kReconMaxThreads) __attribute__((amdgpu_waves_per_eu(TYPE == 3 && SPARSE && !ALPHA ? 7 : 4)))
+__global__ __launch_bounds__(kReconMaxThreads) __attribute__((amdgpu_waves_per_eu(TYPE == 3 && !ALPHA && (SPARSE || LEON_CARRY) ? 7 : 4)))
 void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
                                                                     const Tables* __restrict__ T)
 {
@@ -1093,25 +1119,26 @@ void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
     const int Rt = div_inv(t, G.inv_gC), gc = t - Rt * G.gC;
     Display dsp{lds + kOffStash, 0, lds + kLdsPerWaveDisplay, reinterpret_cast<const char*>(lut_s)};
     stage_tables(T, lds, lane);
-    if (live) recon_task<TYPE, true, SPARSE, true>(pd, G, Rt, gc, lds, lane, dsp);
+    MbCarry carry{};
+    if (live) recon_task<TYPE, true, SPARSE, true, 0, LEON_CARRY ? 1 : 0>(pd, G, Rt, gc, lds, lane, dsp, carry);
     __syncthreads();
     if (!live) return;
     // the two luma parts as two calls, not a loop: the loop form keeps 15 more registers live (B path: 93).
     // yuva: the A part of the same four macroblocks first (AMODE 1), then the Y part that displays them (AMODE 2).
     dsp.side = 0;
     if constexpr (ALPHA) {
-        recon_task<TYPE, false, SPARSE, true, 1>(pd, G, Rt, 2 * gc, lds, lane, dsp, true);
-        recon_task<TYPE, false, SPARSE, true, 2>(pd, G, Rt, 2 * gc, lds, lane, dsp);
+        recon_task<TYPE, false, SPARSE, true, 1, LEON_CARRY ? 2 : 0>(pd, G, Rt, 2 * gc, lds, lane, dsp, carry, true);
+        recon_task<TYPE, false, SPARSE, true, 2, LEON_CARRY ? 2 : 0>(pd, G, Rt, 2 * gc, lds, lane, dsp, carry);
     } else {
-        recon_task<TYPE, false, SPARSE, true>(pd, G, Rt, 2 * gc, lds, lane, dsp);
+        recon_task<TYPE, false, SPARSE, true, 0, LEON_CARRY ? 2 : 0>(pd, G, Rt, 2 * gc, lds, lane, dsp, carry);
     }
     if (2 * gc + 1 < G.gY) {
         dsp.side = 1;
         if constexpr (ALPHA) {
-            recon_task<TYPE, false, SPARSE, true, 1>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp, true);
-            recon_task<TYPE, false, SPARSE, true, 2>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp);
+            recon_task<TYPE, false, SPARSE, true, 1, LEON_CARRY ? 2 : 0>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp, carry, true);
+            recon_task<TYPE, false, SPARSE, true, 2, LEON_CARRY ? 2 : 0>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp, carry);
         } else {
-            recon_task<TYPE, false, SPARSE, true>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp);
+            recon_task<TYPE, false, SPARSE, true, 0, LEON_CARRY ? 2 : 0>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp, carry);
         }
     }
 }
