@@ -96,6 +96,7 @@ struct leon_pipeline {
     hipStream_t vlc_stream[2] = {nullptr, nullptr};
     leon::VlcTables* d_vlc_tables = nullptr;
     leon::VlcGeom vgeom{};
+    size_t vlc_index_lds = 0;         // dynamic LDS of k_vlc_index: the group counters of one picture + its scan
     std::vector<VlcRing> vlc_ring;
 
     std::mutex mu;
@@ -184,8 +185,8 @@ bool same_sequence(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, uint64_t 
 // gpu_parser: the host reads the picture layer only (leon_vlc_scan_picture) and lays the GOP's arena out for the
 // device kernels of leon_vlc_gpu.h:
 //   [stream bytes, zero padded]                                            uploaded
-//   per picture: [error word | group counters | maps]                      cleared on the device
-//   per picture: [grp_off | entries (capacity)], per slice: [scratch]      written by the kernels
+//   per picture: [macroblock records]                                      cleared on the device
+//   per picture: [maps | grp_off | entries (capacity)], per slice: [block records]      written by the kernels
 void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const uint8_t* bytes, size_t n, uint64_t g)
 {
     struct Scan { leon_vlc_picture_scan s; std::vector<int32_t> code; std::vector<uint64_t> pos; };
@@ -215,11 +216,12 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
     if (n >= ((size_t)1 << 28)) { job->status = LEON_ERR_INVALID; job->err = "GOP shard too large for the GPU parser"; return; }
     const size_t mbs = (size_t)p->vinfo.mb_width * p->vinfo.mb_height;
     const size_t mpad = pad256(mbs), vpad = pad256(mbs * 4), gpad = pad256(((size_t)p->vinfo.n_groups + 1) * 4);
+    const size_t rpad = pad256(mbs * leon::kVlcMbRecBytes);
     const size_t max_entries = (size_t)p->vinfo.coded_width * p->vinfo.coded_height * (p->vinfo.has_alpha == 1 ? 5 : 3) / 2;
     const size_t stream_pad = pad256(n + 16);
     // sizes first: the arena may move when it grows
-    const size_t zero_per_pic = gpad + 4 * mpad + 2 * vpad;
-    size_t need = stream_pad + scans.size() * zero_per_pic;
+    const size_t maps_per_pic = 4 * mpad + 2 * vpad;
+    size_t need = stream_pad + scans.size() * (rpad + maps_per_pic);
     std::vector<size_t> ecap(scans.size());
     std::vector<std::vector<size_t>> scap(scans.size());
     for (size_t k = 0; k < scans.size(); k++) {
@@ -242,8 +244,8 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
     memset(a->host + n, 0, stream_pad - n);
     job->upload_bytes = stream_pad;
     size_t at = stream_pad;
-    job->zero_begin = at;
-    job->zero_bytes = scans.size() * zero_per_pic;
+    job->zero_begin = at;                                // the macroblock records of all its pictures, side by side
+    job->zero_bytes = scans.size() * rpad;
     char* dev = a->dev;
     auto take = [&](size_t bytes_) { const size_t o = at; at += bytes_; return o; };
     for (size_t k = 0; k < scans.size(); k++) {
@@ -256,13 +258,7 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
         v.type = x.s.type;
         v.full_pel_fwd = x.s.full_pel_fwd; v.fwd_rsize = x.s.fwd_rsize;
         v.full_pel_bwd = x.s.full_pel_bwd; v.bwd_rsize = x.s.bwd_rsize;
-        v.zbase = dev + take(gpad);                      // [counters | qscale | intra | repadd | mb_dir | mv_fwd | mv_bwd]: VlcGeom's offsets
-        m.qscale = take(mpad); m.intra = take(mpad);
-        const size_t ra = take(mpad), md = take(mpad), mf = take(vpad), mk = take(vpad);
-        m.repadd = x.s.type != LEON_PIC_I ? ra : kNone;
-        m.mb_dir = x.s.type == LEON_PIC_B ? md : kNone;
-        m.mv_fwd = x.s.type != LEON_PIC_I ? mf : kNone;
-        m.mv_bwd = x.s.type == LEON_PIC_B ? mk : kNone;
+        v.zbase = dev + take(rpad);
         job->pics.push_back(m);
         job->vpics.push_back(v);
     }
@@ -270,6 +266,13 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
         const Scan& x = scans[k];
         PipePic& m = job->pics[k];
         leon::VlcPic& v = job->vpics[k];
+        v.maps = dev + at;                               // [qscale | intra | repadd | mb_dir | mv_fwd | mv_bwd]: VlcGeom's offsets
+        m.qscale = take(mpad); m.intra = take(mpad);
+        const size_t ra = take(mpad), md = take(mpad), mf = take(vpad), mk = take(vpad);
+        m.repadd = x.s.type != LEON_PIC_I ? ra : kNone;
+        m.mb_dir = x.s.type == LEON_PIC_B ? md : kNone;
+        m.mv_fwd = x.s.type != LEON_PIC_I ? mf : kNone;
+        m.mv_bwd = x.s.type == LEON_PIC_B ? mk : kNone;
         m.grp_off = take(gpad);
         m.entries = take(pad256(ecap[k] * 4 + 4));
         m.n_entries = (uint32_t)ecap[k];                 // the bound of the device lists (the kernels keep inside it)
@@ -426,7 +429,7 @@ inline size_t vlc_stream_of(int64_t window)
     return one ? 0 : (size_t)(window & 1);
 }
 
-// gpu_parser: the slices of the whole window in one launch each of k_vlc_parse / k_vlc_offsets / k_vlc_blocks
+// gpu_parser: the slices of the whole window in one launch each of k_vlc_parse / k_vlc_index / k_vlc_blocks
 // (leon_vlc_gpu.h), on a parser stream, in front of the reconstruction launches that read their output
 int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
 {
@@ -481,35 +484,22 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
         }
         for (const leon::VlcPic& v : job->vpics) hp[pi++] = v;
     }
-    // Inside a type: picture by picture.  (LEON_VLC_ORDER=row puts the k-th slice of every picture side by side instead:
-    // the 64 lanes of a wave then hold slices that are alike, and a wave runs every block loop as long as its longest
-    // lane -- 30 % fewer instructions in all, and 25-30 % SLOWER end to end (round 3, both test streams): the launch
-    // has fewer waves than the chip has room for, it lasts as long as its longest wave, and a wave of 64 long slices is
-    // longer than a wave with one of them.)
-    static const bool by_row = getenv("LEON_VLC_ORDER") && !strcmp(getenv("LEON_VLC_ORDER"), "row");
+    // Inside a type: picture by picture -- a picture's slices stay together (k_vlc_index walks them).  (The k-th slice of
+    // every picture side by side, so that the 64 lanes of a wave hold slices that are alike, was measured in round 3:
+    // 30 % fewer instructions in all, and 25-30 % SLOWER end to end -- the launch has fewer waves than the chip has
+    // room for, it lasts as long as its longest wave, and a wave of 64 long slices is longer than a wave with one.)
     size_t si = 0;
-    for (int type = 1; type <= 3; type++) {
-        uint32_t longest = 0;
+    for (int type = 1; type <= 3; type++)
         for (const PicRun& pr : runs)
-            if (pr.type == type) longest = std::max(longest, pr.n);
-        if (by_row) {
-            for (uint32_t k = 0; k < longest; k++)
-                for (const PicRun& pr : runs)
-                    if (pr.type == type && k < pr.n) {
-                        hs[si] = pr.first[k];
-                        hs[si].pic = pr.pic;
-                        si++;
-                    }
-        } else {
-            for (const PicRun& pr : runs)
-                if (pr.type == type)
-                    for (uint32_t k = 0; k < pr.n; k++) {
-                        hs[si] = pr.first[k];
-                        hs[si].pic = pr.pic;
-                        si++;
-                    }
-        }
-    }
+            if (pr.type == type) {
+                hp[pr.pic].first_slice = (uint32_t)si;
+                hp[pr.pic].n_slices = pr.n;
+                for (uint32_t k = 0; k < pr.n; k++) {
+                    hs[si] = pr.first[k];
+                    hs[si].pic = pr.pic;
+                    si++;
+                }
+            }
     HIP_TRY(hipMemcpyAsync(R.d, R.h, desc_bytes, hipMemcpyHostToDevice, vs));
     HIP_TRY(hipMemsetAsync(d_err, 0, n_pics * 4, vs));
     const leon::VlcClear* dc = (const leon::VlcClear*)(R.d + pad256(n_slices * sizeof(leon::VlcSlice)) + pad256(n_pics * sizeof(leon::VlcPic)));
@@ -517,8 +507,8 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
     const leon::VlcSlice* ds = (const leon::VlcSlice*)R.d;
     const leon::VlcPic* dp = (const leon::VlcPic*)(R.d + pad256(n_slices * sizeof(leon::VlcSlice)));
     const int blocks = (int)((n_slices + 255) / 256);
-    hipLaunchKernelGGL(leon::k_vlc_parse, dim3(blocks), dim3(256), 0, vs, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
-    hipLaunchKernelGGL(leon::k_vlc_offsets, dim3((unsigned)n_pics), dim3(256), 0, vs, dp, p->vgeom);
+    hipLaunchKernelGGL(leon::k_vlc_parse, dim3(blocks), dim3(256), 4 * leon::kVlcRingDwords * 64 * 4, vs, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
+    hipLaunchKernelGGL(leon::k_vlc_index, dim3((unsigned)n_pics), dim3(leon::kVlcIndexThreads), p->vlc_index_lds, vs, ds, d_words, dp, p->vgeom);
     hipLaunchKernelGGL(leon::k_vlc_blocks, dim3((unsigned)((n_slices + 3) / 4)), dim3(256), 0, vs, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(R.h_err, d_err, n_pics * 4, hipMemcpyDeviceToHost, vs));
@@ -1025,17 +1015,22 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
         p->vgeom.n_c = p->vinfo.mb_height * p->vinfo.groups_c;
         p->vgeom.n_groups = p->vinfo.n_groups;
         p->vgeom.alpha = p->vinfo.has_alpha == 1;
-        {   // a picture's counters and maps, in the order scan_gop_for_gpu lays them out
+        {   // a picture's maps, in the order scan_gop_for_gpu lays them out
             const size_t mbs = (size_t)p->vinfo.mb_width * p->vinfo.mb_height;
-            const size_t mpad = pad256(mbs), vpad = pad256(mbs * 4), gpad = pad256(((size_t)p->vinfo.n_groups + 1) * 4);
-            p->vgeom.off_cnt = 0;
-            p->vgeom.off_qscale = (uint32_t)gpad;
-            p->vgeom.off_intra = (uint32_t)(gpad + mpad);
-            p->vgeom.off_repadd = (uint32_t)(gpad + 2 * mpad);
-            p->vgeom.off_mb_dir = (uint32_t)(gpad + 3 * mpad);
-            p->vgeom.off_mv_fwd = (uint32_t)(gpad + 4 * mpad);
-            p->vgeom.off_mv_bwd = (uint32_t)(gpad + 4 * mpad + vpad);
+            const size_t mpad = pad256(mbs), vpad = pad256(mbs * 4);
+            p->vgeom.off_qscale = 0;
+            p->vgeom.off_intra = (uint32_t)mpad;
+            p->vgeom.off_repadd = (uint32_t)(2 * mpad);
+            p->vgeom.off_mb_dir = (uint32_t)(3 * mpad);
+            p->vgeom.off_mv_fwd = (uint32_t)(4 * mpad);
+            p->vgeom.off_mv_bwd = (uint32_t)(4 * mpad + vpad);
         }
+        // k_vlc_index counts a picture's groups in LDS (one workgroup may have all 160 KiB of a CU)
+        p->vlc_index_lds = ((size_t)p->vinfo.n_groups + leon::kVlcIndexThreads) * 4;
+        if (p->vlc_index_lds > 160 * 1024 - 512) return bail(LEON_ERR_INVALID, "picture too large for the GPU parser (its group counters do not fit in LDS): use LEON_PIPELINE_PARSER_HOST");
+        if (p->vlc_index_lds > 48 * 1024 &&
+            hipFuncSetAttribute((const void*)leon::k_vlc_index, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->vlc_index_lds) != hipSuccess)
+            return bail(LEON_ERR_HIP, "LDS of the GPU parser's index kernel");
         p->vlc_ring.resize((size_t)p->R);
     }
     const int n_arenas = p->W * (p->R + 1);

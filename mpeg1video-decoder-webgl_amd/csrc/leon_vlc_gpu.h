@@ -12,16 +12,17 @@
 // 128 GOPs x 12 pictures: ~100 000 independent slices, one LANE each.  16 host cores parse 14 k pictures/s;
 // the reconstruction kernels take 220 k/s.
 //
-//   k_vlc_parse    one lane per slice, the SERIAL part only: macroblock headers and vectors (maps straight into the
-//                  picture's arrays), DC values, and for every coded block WHERE its coefficient symbols begin and how
+//   k_vlc_parse    one lane per slice, the SERIAL part only: macroblock headers and vectors (ONE 16-byte record per
+//                  macroblock), DC values, and for every coded block WHERE its coefficient symbols begin and how
 //                  many there are -- the symbols themselves are stepped over, several at a time (one table lookup on
 //                  12 bits gives the bits, the number of symbols and the positions they advance, up to the end of
-//                  block).  One 12-byte record per coded block into the slice's strip, its count added to the group's counter.
-//   k_vlc_offsets  one workgroup per picture: exclusive scan of the group counters -> grp_off (what
-//                  leon_sparse_picture wants), counters back to zero (they become cursors).
+//                  block).  One 16-byte record per coded block into the slice's strip.  No atomics.
+//   k_vlc_index    one workgroup per picture: counts the entries of every group from the block records (LDS atomics;
+//                  a record learns its block's place inside the group), exclusive scan -> grp_off (what
+//                  leon_sparse_picture wants), and turns the macroblock records into the maps (whole lines).
 //   k_vlc_blocks   the PARALLEL part, one lane per coded block (a wave walks the records of one slice, 64 at a time):
-//                  decodes the block's symbols from its bit position and writes the entries to grp_off[group] + cursor
-//                  (atomic add of the block's count).  Entries of a group are "in no particular order" (include/leon_vlc.h).
+//                  decodes the block's symbols from its bit position and writes the entries to grp_off[group] + place.
+//                  Entries of a group are "in no particular order" (include/leon_vlc.h).
 // Round 2 decoded the coefficients in the slice loop (one kernel + a gather): a launch lasted as long as its longest
 // slice, symbol after symbol, 170 ns each.  A block's end can only be found by reading its symbols' LENGTHS in order --
 // but nothing else of them is needed there.
@@ -35,7 +36,11 @@ namespace leon {
 // counts on the LDS counter too -- and the wait in front of the next table lookup (LDS) then waits for the entry
 // stored a symbol earlier to reach memory.
 #define VLC_G __attribute__((address_space(1)))
+typedef uint32_t vlc_u4 __attribute__((ext_vector_type(4)));      // a 16-byte record (HIP's uint4 is a class: no address-space pointers to it)
 
+#ifndef LEON_VLC_WAVES
+#define LEON_VLC_WAVES 4
+#endif
 #ifndef LEON_VLC_MULTI_BITS
 #define LEON_VLC_MULTI_BITS 12
 #endif
@@ -66,23 +71,33 @@ static constexpr int kVlcLdsWords = (kVlcMulti + 512 + 2048 + 2048 + 512 + 256 +
 // every lane reads its slice through a ring of 16 dwords in LDS: dword i of lane L at ring[(i & 15) * 64 + L]
 static constexpr int kVlcRingDwords = 16;
 // a coded block as k_vlc_parse hands it to k_vlc_blocks: {bit position of its first coefficient symbol (behind the DC of an
-// intra block), group | block of the group << 20 | intra << 23 | entries << 24, DC level | has one << 16}
-static constexpr int kVlcRecWords = 3;
+// intra block), group | block of the group << 20 | intra << 23 | entries << 24, DC level | has one << 16, where its entries
+// begin inside the group's list (filled in by k_vlc_index)} -- 16 bytes, one store
+static constexpr int kVlcRecWords = 4;
+// a macroblock as k_vlc_parse hands it to k_vlc_index: {quantiser scale | intra << 8 | RepAdd 255 << 9 | direction << 10,
+// forward vector, backward vector, 0} -- ONE 16-byte store per macroblock into the picture's record array (index = macroblock
+// address) instead of up to six scattered byte / word stores into six maps: the slice loop's stores leave the L2 as partial
+// lines (a lane comes back to a line long after the reconstruction launches beside it have flushed it), round 3 counted 113 M
+// write requests to memory per 1536-picture window, a tenth of them whole lines -- three times what the largest
+// reconstruction launch writes -- and the kernels beside the parser ran at half speed
+static constexpr int kVlcMbRecBytes = 16;
 static constexpr int kVlcRingBytesPerWave = kVlcRingDwords * 64 * 4;
 
 struct VlcGeom {
     int32_t mbw, mbh, gy, gc, n_y, n_c, n_groups, alpha;
-    // byte offsets of a picture's arrays from VlcPic::zbase (the same for every picture: wave-uniform)
-    uint32_t off_cnt, off_qscale, off_intra, off_repadd, off_mb_dir, off_mv_fwd, off_mv_bwd, pad;
+    // byte offsets of a picture's maps from VlcPic::maps (the same for every picture: wave-uniform)
+    uint32_t off_qscale, off_intra, off_repadd, off_mb_dir, off_mv_fwd, off_mv_bwd, pad0, pad1;
 };
 
 struct VlcPic {                  // one picture of the window
-    int32_t type, full_pel_fwd, fwd_rsize, full_pel_bwd, bwd_rsize, pad;
-    char* zbase;                 // zero on entry: group counters [n_groups + 1] and the macroblock maps, at VlcGeom's offsets
+    int32_t type, full_pel_fwd, fwd_rsize, full_pel_bwd, bwd_rsize;
+    uint32_t first_slice;        // its slices in the launch's slice array: [first_slice, first_slice + n_slices)
+    char* zbase;                 // zero on entry: the macroblock records [mbw * mbh] of kVlcMbRecBytes
+    char* maps;                  // the macroblock maps k_vlc_index writes, at VlcGeom's offsets
     uint32_t* grp_off;           // [n_groups + 1]
     uint32_t* entries;
     uint32_t entries_cap;
-    uint32_t pad2;
+    uint32_t n_slices;
 };
 
 struct VlcSlice {
@@ -214,7 +229,7 @@ struct VlcCtx {                  // per lane: the state a slice carries from mac
     int mb_intra;
     VLC_G uint32_t* hdr;         // next free block record of the slice's strip
     VLC_G uint32_t* hdr_end;
-    VLC_G char* zbase;           // the picture's counters and maps
+    VLC_G char* zbase;           // the picture's macroblock records
     int type, full_pel_fwd, fwd_rsize, full_pel_bwd, bwd_rsize;
     uint32_t* wave_ring;         // LDS ring of the wave (VlcWin::sync)
     int lane;
@@ -328,11 +343,8 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcGe
     }
     if (r.pos > (uint32_t)(r.nd << 5)) return VLC_ERR_END;     // ran off the data (zeros behind it: an invalid code ended the loop at the latest)
     if (k) {
-        c.hdr[0] = start;
-        c.hdr[1] = gid | (bq << 20) | (c.mb_intra ? 1u << 23 : 0u) | ((uint32_t)k << 24);
-        c.hdr[2] = dcw;
+        *reinterpret_cast<VLC_G vlc_u4*>(c.hdr) = vlc_u4{start, gid | (bq << 20) | (c.mb_intra ? 1u << 23 : 0u) | ((uint32_t)k << 24), dcw, 0u};
         c.hdr += kVlcRecWords;
-        __hip_atomic_fetch_add(reinterpret_cast<VLC_G uint32_t*>(c.zbase + G.off_cnt) + gid, (uint32_t)k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
     return 0;
 }
@@ -356,12 +368,7 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
                                               bool& slice_begin)
 {
     const int type = c.type, mbsize = G.mbw * G.mbh;
-    VLC_G uint8_t* const m_qscale = reinterpret_cast<VLC_G uint8_t*>(c.zbase + G.off_qscale);
-    VLC_G uint8_t* const m_intra = reinterpret_cast<VLC_G uint8_t*>(c.zbase + G.off_intra);
-    VLC_G uint8_t* const m_repadd = reinterpret_cast<VLC_G uint8_t*>(c.zbase + G.off_repadd);
-    VLC_G uint8_t* const m_mb_dir = reinterpret_cast<VLC_G uint8_t*>(c.zbase + G.off_mb_dir);
-    VLC_G uint32_t* const m_mv_fwd = reinterpret_cast<VLC_G uint32_t*>(c.zbase + G.off_mv_fwd);      // (h, v) int16 pairs as one word
-    VLC_G uint32_t* const m_mv_bwd = reinterpret_cast<VLC_G uint32_t*>(c.zbase + G.off_mv_bwd);
+    VLC_G vlc_u4* const mbrec = reinterpret_cast<VLC_G vlc_u4*>(c.zbase);        // kVlcMbRecBytes per macroblock
 
     int increment = 0, t;
     t = vlc_mba(r, L, c);
@@ -379,12 +386,8 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
             if (type == 2) { c.fw_h = c.fw_h_prev = 0; c.fw_v = c.fw_v_prev = 0; }
         }
         while (increment > 1) {                              // skipped macroblocks
-            const int a = ++c.mb_addr;
-            if (type != 1) m_mv_fwd[a] = vlc_mv_word(c.fw_h, c.fw_v);
-            if (type == 3) {
-                m_mv_bwd[a] = vlc_mv_word(c.bw_h, c.bw_v);
-                m_mb_dir[a] = (uint8_t)c.prev_dir;
-            }
+            const int a = ++c.mb_addr;                          // (c.bw_*, c.prev_dir stay 0 outside B pictures)
+            mbrec[a] = vlc_u4{(uint32_t)c.prev_dir << 10, vlc_mv_word(c.fw_h, c.fw_v), vlc_mv_word(c.bw_h, c.bw_v), 0u};
             increment--;
         }
         c.mb_addr++;
@@ -403,13 +406,10 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
     c.mb_intra = mb_type & 0x01;
     const int mot_fw = mb_type & 0x08, mot_bw = mb_type & 0x04;
     if (mb_type & 0x10) c.qs = (int)r.get(5);                 // type (<= 6 bits) and quantiser_scale: one dword at most
-    m_qscale[mb] = (uint8_t)c.qs;
-    m_intra[mb] = c.mb_intra ? 255 : 0;
     if (c.mb_intra) {
         c.fw_h = c.fw_h_prev = 0; c.fw_v = c.fw_v_prev = 0;
         c.bw_h = c.bw_h_prev = 0; c.bw_v = c.bw_v_prev = 0;
         c.prev_dir = 0;
-        if (type != 1) m_repadd[mb] = 255;                   // jsv.js:1502-1505
     } else {
         c.dc_y = c.dc_cr = c.dc_cb = c.dc_a = 128;
         int err = 0;
@@ -433,13 +433,11 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
             c.bw_v = c.full_pel_bwd ? c.bw_v_prev * 2 : c.bw_v_prev;
         }
         if (err) return err + 1;
-        if (type != 1) m_mv_fwd[mb] = vlc_mv_word(c.fw_h, c.fw_v);
-        if (type == 3) {
-            m_mv_bwd[mb] = vlc_mv_word(c.bw_h, c.bw_v);
-            c.prev_dir = (mot_fw ? 1 : 0) | (mot_bw ? 2 : 0);
-            m_mb_dir[mb] = (uint8_t)c.prev_dir;
-        }
+        if (type == 3) c.prev_dir = (mot_fw ? 1 : 0) | (mot_bw ? 2 : 0);
     }
+    // quantiser scale | intra | RepAdd 255 of an intra macroblock outside I pictures (jsv.js:1502-1505) | direction, vectors
+    mbrec[mb] = vlc_u4{(uint32_t)(c.qs & 0xff) | (c.mb_intra ? (type != 1 ? 0x300u : 0x100u) : (uint32_t)c.prev_dir << 10),
+                      vlc_mv_word(c.fw_h, c.fw_v), vlc_mv_word(c.bw_h, c.bw_v), 0u};
     int cbp = 0;
     VLC_SYNC(r, c);
     if (mb_type & 0x02) {
@@ -463,12 +461,12 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
 }
 
 // LDS (tables 18.4 KB + four rings of 4 KB per workgroup) allows four waves per SIMD: let the registers go that far too
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_vlc_parse(const VlcSlice* __restrict__ slices, uint32_t* __restrict__ slice_words, int n_slices,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEON_VLC_WAVES, LEON_VLC_WAVES))) void k_vlc_parse(const VlcSlice* __restrict__ slices, uint32_t* __restrict__ slice_words, int n_slices,
                                                    const VlcPic* __restrict__ pics, uint32_t* __restrict__ errors, VlcGeom G,
                                                    const VlcTables* __restrict__ T)
 {
     __shared__ VlcLds L;
-    __shared__ __attribute__((aligned(16))) uint32_t rings[4 * kVlcRingDwords * 64];
+    extern __shared__ __attribute__((aligned(16))) uint32_t rings[];          // 4 * kVlcRingDwords * 64 dwords, given at the launch
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(T);
         uint32_t* dst = reinterpret_cast<uint32_t*>(&L);
@@ -529,37 +527,100 @@ __global__ __launch_bounds__(256) void k_vlc_clear(const VlcClear* __restrict__ 
     for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < R.n16; i += (uint64_t)gridDim.x * 256) R.ptr[i] = uint4{0u, 0u, 0u, 0u};
 }
 
-// exclusive scan of a picture's group counters; the counters go back to zero (k_vlc_blocks' cursors)
-__global__ __launch_bounds__(256) void k_vlc_offsets(const VlcPic* __restrict__ pics, VlcGeom G)
+// Between the two passes, a workgroup per picture:
+//  * the entries of every group are counted from the block records of the picture's slices -- in LDS, so that neither pass
+//    needs a global atomic (agent-scope atomics are write-through on a chip with one L2 per XCD: round 3 counted one
+//    uncached 32-byte write per coded block, 32 M per window, in k_vlc_parse and again in k_vlc_blocks) -- and every
+//    record learns where its block's entries begin inside the group's list (the counter's value before it was added);
+//  * exclusive scan of the counters -> grp_off;
+//  * the macroblock records become the maps the reconstruction reads (qscale, intra, RepAdd, direction, vectors), lane
+//    after lane along the macroblock address: whole lines.
+// Dynamic LDS: n_groups counters + a word per wave.
+static constexpr int kVlcIndexThreads = 256;      // small workgroups: beside the reconstruction launches a 1024-thread one waited for 16 free wave slots on ONE CU
+__global__ __launch_bounds__(kVlcIndexThreads) void k_vlc_index(const VlcSlice* __restrict__ slices, const uint32_t* __restrict__ slice_blocks,
+                                                                const VlcPic* __restrict__ pics, VlcGeom G)
 {
-    __shared__ uint32_t part[256];
+    extern __shared__ uint32_t s_index[];
+    const int ng = G.n_groups, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    uint32_t* const cnt = s_index;
+    uint32_t* const part = s_index + ng;
     const VlcPic P = pics[blockIdx.x];
-    uint32_t* const cnt = reinterpret_cast<uint32_t*>(P.zbase + G.off_cnt);
-    const int ng = G.n_groups, per = (ng + 255) / 256;
-    const int lo = min((int)threadIdx.x * per, ng), hi = min(lo + per, ng);
+    for (int g = tid; g < ng; g += kVlcIndexThreads) cnt[g] = 0u;
+    __syncthreads();
+    // a wave per slice, a lane per record, four records of a lane in flight
+    for (uint32_t sidx = (uint32_t)wv; sidx < P.n_slices; sidx += kVlcIndexThreads / 64) {
+        const VlcSlice* S = slices + P.first_slice + sidx;
+        const uint32_t n_blocks = min(slice_blocks[P.first_slice + sidx], S->hdr_cap);
+        uint32_t* const rec = S->scratch;
+        for (uint32_t b0 = (uint32_t)lane; b0 < n_blocks; b0 += 256) {
+            uint32_t r1[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) r1[u] = b0 + 64u * u < n_blocks ? rec[(b0 + 64u * u) * kVlcRecWords + 1] : 0u;
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const uint32_t gid = r1[u] & 0xfffffu, k = r1[u] >> 24;
+                if (b0 + 64u * u < n_blocks && gid < (uint32_t)ng && k <= 64u) rec[(b0 + 64u * u) * kVlcRecWords + 3] = atomicAdd(cnt + gid, k);
+            }
+        }
+    }
+    __syncthreads();
+    // exclusive scan of the counters, in place: a thread sums `per` neighbours, the 256 sums are scanned by shuffles
+    const int per = (ng + kVlcIndexThreads - 1) / kVlcIndexThreads;
+    const int lo = min(tid * per, ng), hi = min(lo + per, ng);
     uint32_t sum = 0;
     for (int g = lo; g < hi; g++) sum += cnt[g];
-    part[threadIdx.x] = sum;
-    __syncthreads();
-    for (int d = 1; d < 256; d <<= 1) {                       // inclusive scan of the 256 partial sums
-        const uint32_t v = threadIdx.x >= (unsigned)d ? part[threadIdx.x - d] : 0u;
-        __syncthreads();
-        part[threadIdx.x] += v;
-        __syncthreads();
+    uint32_t incl = sum;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t v = __shfl_up(incl, d, 64);
+        if (lane >= d) incl += v;
     }
-    uint32_t run = part[threadIdx.x] - sum;
+    if (lane == 63) part[wv] = incl;
+    __syncthreads();
+    uint32_t run = incl - sum;
+    for (int w = 0; w < wv; w++) run += part[w];
     for (int g = lo; g < hi; g++) {
         const uint32_t n = cnt[g];
-        P.grp_off[g] = run;
-        cnt[g] = 0;
+        cnt[g] = run;
         run += n;
     }
-    if (threadIdx.x == 255) P.grp_off[ng] = part[255];
+    __syncthreads();
+    for (int g = tid; g < ng; g += kVlcIndexThreads) P.grp_off[g] = cnt[g];
+    if (tid == kVlcIndexThreads - 1) P.grp_off[ng] = run;
+    // the maps, four macroblocks of a lane in flight
+    const int mbs = G.mbw * G.mbh;
+    const uint4* const mbrec = reinterpret_cast<const uint4*>(P.zbase);
+    uint8_t* const m_qscale = reinterpret_cast<uint8_t*>(P.maps + G.off_qscale);
+    uint8_t* const m_intra = reinterpret_cast<uint8_t*>(P.maps + G.off_intra);
+    uint8_t* const m_repadd = reinterpret_cast<uint8_t*>(P.maps + G.off_repadd);
+    uint8_t* const m_mb_dir = reinterpret_cast<uint8_t*>(P.maps + G.off_mb_dir);
+    uint32_t* const m_mv_fwd = reinterpret_cast<uint32_t*>(P.maps + G.off_mv_fwd);
+    uint32_t* const m_mv_bwd = reinterpret_cast<uint32_t*>(P.maps + G.off_mv_bwd);
+    for (int mb0 = tid; mb0 < mbs; mb0 += 4 * kVlcIndexThreads) {
+        uint4 m[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) m[u] = mb0 + u * kVlcIndexThreads < mbs ? mbrec[mb0 + u * kVlcIndexThreads] : uint4{0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int mb = mb0 + u * kVlcIndexThreads;
+            if (mb >= mbs) break;
+            m_qscale[mb] = (uint8_t)m[u].x;
+            m_intra[mb] = (m[u].x & 0x100u) ? 255 : 0;
+            if (P.type != 1) {
+                m_repadd[mb] = (m[u].x & 0x200u) ? 255 : 0;
+                m_mv_fwd[mb] = m[u].y;
+            }
+            if (P.type == 3) {
+                m_mb_dir[mb] = (uint8_t)((m[u].x >> 10) & 3u);
+                m_mv_bwd[mb] = m[u].z;
+            }
+        }
+    }
 }
 
 // The parallel half: the symbols of every coded block, a lane per block.  One WAVE per slice walks the slice's records 64
 // at a time; a lane reads its block's bits straight from memory (three dwords cover most blocks), decodes run / level
-// pairs until the end-of-block code and writes them as entries (tile offset << 16 | level) to grp_off[group] + cursor.
+// pairs until the end-of-block code and writes them as entries (tile offset << 16 | level) to grp_off[group] + its place.
 // Same symbol reading as leon_vlc.cpp's decode_block; a block that does not read the way k_vlc_parse counted it (it
 // cannot, both read the same bits with the same tables) sets the picture's error word instead of leaving entries undefined.
 __global__ __launch_bounds__(256) void k_vlc_blocks(const VlcSlice* __restrict__ slices, const uint32_t* __restrict__ slice_blocks, int n_slices,
@@ -577,7 +638,6 @@ __global__ __launch_bounds__(256) void k_vlc_blocks(const VlcSlice* __restrict__
     if (j >= n_slices) return;
     const VlcSlice S = slices[j];
     const VlcPic P = pics[S.pic];
-    VLC_G uint32_t* const cursor = reinterpret_cast<VLC_G uint32_t*>((VLC_G char*)P.zbase + G.off_cnt);
     const uint32_t n_blocks = min(slice_blocks[j], S.hdr_cap);
     const VLC_G uint32_t* const rec = (const VLC_G uint32_t*)S.scratch;
     const VLC_G uint32_t* const bytes = (const VLC_G uint32_t*)S.bytes;
@@ -587,12 +647,13 @@ __global__ __launch_bounds__(256) void k_vlc_blocks(const VlcSlice* __restrict__
     for (uint32_t base = 0; base < n_blocks; base += 64) {
         const uint32_t b = base + (uint32_t)lane;
         if (b >= n_blocks) continue;
-        const uint32_t bit = rec[b * kVlcRecWords], r1 = rec[b * kVlcRecWords + 1], dcw = rec[b * kVlcRecWords + 2];
+        const vlc_u4 rc = reinterpret_cast<const VLC_G vlc_u4*>(rec)[b];
+        const uint32_t bit = rc.x, r1 = rc.y, dcw = rc.z;
         const uint32_t gid = r1 & 0xfffffu, bq = (r1 >> 20) & 7u, k = r1 >> 24;
         const bool intra = (r1 >> 23) & 1u;
-        if (k == 0u || k > 64u) continue;
-        const uint32_t at = grp_off[gid] + __hip_atomic_fetch_add(cursor + gid, k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (at + k > P.entries_cap) { err = VLC_ERR_SCRATCH; continue; }
+        if (k == 0u || k > 64u || gid >= (uint32_t)G.n_groups) continue;
+        const uint32_t at = grp_off[gid] + rc.w;              // k_vlc_index: the group's list, this block's place in it
+        if (at + k > P.entries_cap || at + k < at) { err = VLC_ERR_SCRATCH; continue; }
         VLC_G uint32_t* out = entries + at;
         const uint32_t bbase = (bq * 16u) << 16;
         // the lane's window: 64 bits from `bit` on, refilled a dword at a time

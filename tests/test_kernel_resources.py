@@ -26,7 +26,7 @@ BUDGET = {
     "k_recon_displayILi1ELb1ELb1E": 64, "k_recon_displayILi2ELb1ELb1E": 72, "k_recon_displayILi3ELb1ELb1E": 88,
     # the GPU parser: LDS allows 4 waves per SIMD = 128 registers; NO scratch -- a DC predictor (or anything else of the
     # lane's context) read through a computed address puts the whole context there and costs a quarter of the speed
-    "k_vlc_parse": 128, "k_vlc_blocks": 64, "k_vlc_offsets": 64,
+    "k_vlc_parse": 128, "k_vlc_blocks": 64, "k_vlc_index": 64,
 }
 
 
