@@ -96,6 +96,12 @@ int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_strea
  * leon_vlc_info.has_alpha of the whole stream (the `a` flag is in the container header, jsv.js:256-259,
  * which a shard does not carry).  Ignored when the bytes start with a container header of their own. */
 int leon_vlc_open_shard(const uint8_t* data, size_t n, int32_t threads, int32_t has_alpha, leon_vlc_stream** out);
+/* A stream for leon_vlc_scan_picture only (the pipeline's gpu_parser mode: the host reads the layers above the slices,
+ * a few dozen bytes per picture, and finds the slice start codes): when `readable` >= n + 16 bytes may be read from
+ * `data` (what lies behind the n bytes does not matter), NOTHING is copied and no read-ahead thread is started -- `data`
+ * must then stay valid until leon_vlc_close; leon_vlc_next_picture* are refused.  Opening and closing a 1.2 MB GOP shard
+ * the ordinary way (copy, thread) cost more than scanning its twelve pictures. */
+int leon_vlc_open_scan(const uint8_t* data, size_t n, size_t readable, int32_t has_alpha, leon_vlc_stream** out);
 void leon_vlc_close(leon_vlc_stream* s);
 int leon_vlc_get_info(leon_vlc_stream* s, leon_vlc_info* out);
 

@@ -27,6 +27,7 @@ struct Arena {                   // pinned host buffer + its device twin, one GO
     char* host = nullptr;
     char* dev = nullptr;
     size_t cap = 0, host_cap = 0, used = 0;      // cap: of the device twin
+    bool host_owned = true, dev_owned = true;    // false: a piece of the pipeline's slabs (gpu_parser), not to be freed
 };
 
 struct GopJob {
@@ -82,6 +83,7 @@ struct leon_pipeline {
     std::vector<uint32_t> mine;                       // key-map ids this pipeline decodes (all, or g % shard_count == shard_index)
     uint64_t total_gops = 0;                          // gops * loop
     int W = 32, R = 2, K = 1, max_pics = 16;
+    std::vector<double> st_window_done;                      // LEON_DEBUG_PIPE_TIMING: when each window completed (seconds from the start)
     uint64_t st_wait_ring_ns = 0, st_wait_scan_ns = 0;       // submit thread: waiting for a ring entry / for the window's GOPs to be parsed
     bool unfused = false;        // frame_width % 8 != 0: planes for every picture, one display conversion launch per picture
     size_t frame_bytes = 0;
@@ -96,6 +98,8 @@ struct leon_pipeline {
     hipStream_t vlc_stream[2] = {nullptr, nullptr};
     leon::VlcTables* d_vlc_tables = nullptr;
     leon::VlcGeom vgeom{};
+    char* slab_host = nullptr;        // gpu_parser: the arenas' memory, one allocation each (pinned host, device)
+    char* slab_dev = nullptr;
     size_t vlc_index_lds = 0;         // dynamic LDS of k_vlc_index: the group counters of one picture + its scan
     std::vector<VlcRing> vlc_ring;
 
@@ -145,17 +149,19 @@ bool arena_reserve(leon_pipeline* p, Arena* a, size_t host_need, size_t dev_need
         char* h = nullptr;
         if (hipHostMalloc((void**)&h, cap, hipHostMallocDefault) != hipSuccess) return false;
         if (a->used) memcpy(h, a->host, std::min(a->used, a->host_cap));
-        if (a->host) hipHostFree(a->host);
+        if (a->host && a->host_owned) hipHostFree(a->host);
         a->host = h;
         a->host_cap = cap;
+        a->host_owned = true;
     }
     if (dev_need > a->cap) {
         const size_t cap = std::max(dev_need + dev_need / 2, (size_t)8 << 20);
         char* dv = nullptr;
         if (hipMalloc((void**)&dv, cap) != hipSuccess) return false;
-        if (a->dev) hipFree(a->dev);        // only ever grown while the arena is being filled: nothing in flight reads it
+        if (a->dev && a->dev_owned) hipFree(a->dev);        // only ever grown while the arena is being filled: nothing in flight reads it
         a->dev = dv;
         a->cap = cap;
+        a->dev_owned = true;
     }
     return true;
 }
@@ -309,7 +315,10 @@ void parse_gop(leon_pipeline* p, GopJob* job)
     const size_t n = (size_t)(p->shard_end[g] - p->shard_begin[g]);
     leon_vlc_stream* st = nullptr;
     // a stream without key map is one shard that still carries its container header
-    if (leon_vlc_open_shard(b, n, 1, p->vinfo.has_alpha, &st) != LEON_VLC_OK) {
+    // gpu_parser: only the picture layer is read here -- in place, when the stream goes on behind the shard
+    const int rc_open = p->gpu_parser ? leon_vlc_open_scan(b, n, p->bytes - (size_t)p->shard_begin[g], p->vinfo.has_alpha, &st)
+                                      : leon_vlc_open_shard(b, n, 1, p->vinfo.has_alpha, &st);
+    if (rc_open != LEON_VLC_OK) {
         job->status = LEON_ERR_INVALID;
         job->err = std::string("GOP shard ") + std::to_string(g) + ": " + leon_vlc_last_error();
         return;
@@ -774,6 +783,7 @@ void notify_main(leon_pipeline* p)
             std::lock_guard<std::mutex> lk(p->mu);
             p->delivered[id] = w;
             p->st_seconds = std::chrono::duration<double>(Clock::now() - p->t0).count();
+            if (p->st_window_done.size() < 4096) p->st_window_done.push_back(p->st_seconds);
             quiet = p->quiet;
         }
         // frames are handed over outside the lock: the callback may release the window at once
@@ -1039,6 +1049,36 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
         p->all_arenas.push_back(a);
         p->free_arenas.push_back(a);
     }
+    if (p->gpu_parser) {
+        // The arenas of the GPU parser come out of two slabs allocated HERE, sized for the largest GOP shard of the key
+        // map (what scan_gop_for_gpu will ask for, from its own bounds: 16 bytes of entry list and 32 of block records per
+        // stream byte, the maps and records of max_gop_pictures pictures, a strip per slice): allocated one by one at
+        // their first use -- and again when a larger GOP came by, hipFree waits for the device -- the first four windows of
+        // a 1080p run took 35-40 ms each instead of 8.6.  A GOP that still does not fit gets an allocation of its own
+        // (arena_reserve); without the memory for the slabs everything does.
+        size_t largest = 0;
+        for (uint64_t g : p->mine) largest = std::max(largest, (size_t)(p->shard_end[g] - p->shard_begin[g]));
+        const size_t mbs = (size_t)p->vinfo.mb_width * p->vinfo.mb_height;
+        const size_t per_pic = pad256(mbs * leon::kVlcMbRecBytes) + 4 * pad256(mbs) + 2 * pad256(mbs * 4) + pad256(((size_t)p->vinfo.n_groups + 1) * 4) + 512 +
+                               2 * (size_t)p->vinfo.mb_height * 512;
+        const size_t host_each = pad256(largest + 16) + 4096;
+        const size_t dev_each = (pad256(largest + 16) + 48 * largest + (size_t)p->max_pics * per_pic + 65535) / 65536 * 65536;
+        size_t free_b = 0, total_b = 0;
+        if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)n_arenas * dev_each < free_b / 2 && !getenv("LEON_DEBUG_NO_SLABS")) {
+            if (hipMalloc((void**)&p->slab_dev, (size_t)n_arenas * dev_each) == hipSuccess &&
+                hipHostMalloc((void**)&p->slab_host, (size_t)n_arenas * host_each, hipHostMallocDefault) == hipSuccess) {
+                for (int i = 0; i < n_arenas; i++) {
+                    Arena* a = p->all_arenas[(size_t)i];
+                    a->dev = p->slab_dev + (size_t)i * dev_each; a->cap = dev_each; a->dev_owned = false;
+                    a->host = p->slab_host + (size_t)i * host_each; a->host_cap = host_each; a->host_owned = false;
+                }
+            } else {
+                if (p->slab_dev) hipFree(p->slab_dev);
+                p->slab_dev = nullptr;
+                (void)hipGetLastError();
+            }
+        }
+    }
     p->t0 = Clock::now();
     for (int i = 0; i < p->K; i++) p->parsers.emplace_back(parser_main, p);
     p->submitter = std::thread(submit_main, p);
@@ -1129,16 +1169,23 @@ void leon_pipeline_destroy(leon_pipeline* p)
         p->parsed.clear();
     }
     for (Arena* a : p->all_arenas) {
-        if (a->host) hipHostFree(a->host);
-        if (a->dev) hipFree(a->dev);
+        if (a->host && a->host_owned) hipHostFree(a->host);
+        if (a->dev && a->dev_owned) hipFree(a->dev);
         delete a;
     }
+    if (p->slab_host) hipHostFree(p->slab_host);
+    if (p->slab_dev) hipFree(p->slab_dev);
     if (getenv("LEON_DEBUG_PIPE_TIMING"))      // where the submit thread's time went (LEON_DEBUG_PIPE_TIMING=1)
         fprintf(stderr, "leon pipeline: %llu windows; per window on the submit thread: %.2f ms waiting for a ring entry, %.2f ms waiting for the window's GOPs "
                         "(parser threads), %.2f ms in submit_window\n", (unsigned long long)p->windows_submitted,
                 p->windows_submitted ? (double)p->st_wait_ring_ns / 1e6 / (double)p->windows_submitted : 0.0,
                 p->windows_submitted ? (double)p->st_wait_scan_ns / 1e6 / (double)p->windows_submitted : 0.0,
                 p->windows_submitted ? (double)p->st_submit_ns.load() / 1e6 / (double)p->windows_submitted : 0.0);
+    if (getenv("LEON_DEBUG_PIPE_TIMING") && !p->st_window_done.empty()) {
+        fprintf(stderr, "leon pipeline: windows completed at (ms):");
+        for (size_t i = 0; i < p->st_window_done.size() && i < 64; i++) fprintf(stderr, " %.1f", p->st_window_done[i] * 1e3);
+        fprintf(stderr, "\n");
+    }
     for (VlcRing& r : p->vlc_ring) {
         if (r.h) hipHostFree(r.h);
         if (r.d) hipFree(r.d);

@@ -7,7 +7,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SYMBOLS = ["leon_vlc_last_error", "leon_vlc_open", "leon_vlc_open_shard", "leon_vlc_close", "leon_vlc_get_info",
+SYMBOLS = ["leon_vlc_last_error", "leon_vlc_open", "leon_vlc_open_shard", "leon_vlc_open_scan", "leon_vlc_close", "leon_vlc_get_info",
            "leon_vlc_next_picture", "leon_vlc_next_picture_sync", "leon_vlc_seek", "leon_vlc_densify", "leon_vlc_densify_alpha", "leon_vlc_get_keymap",
            "leon_vlc_scan_picture", "leon_vlc_get_gpu_tables"]
 
@@ -56,6 +56,7 @@ def load():
     lib.leon_vlc_last_error.restype = C.c_char_p
     lib.leon_vlc_open.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p)]
     lib.leon_vlc_open_shard.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+    lib.leon_vlc_open_scan.argtypes = [C.c_void_p, C.c_size_t, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p)]
     lib.leon_vlc_close.argtypes = [C.c_void_p]
     lib.leon_vlc_close.restype = None
     lib.leon_vlc_get_info.argtypes = [C.c_void_p, C.POINTER(Info)]
@@ -82,13 +83,18 @@ class Stream:
     """One JSV / MPEG-1 video elementary stream; mirrors the decoder object's parsing half
     (decodeFrame / seek of decoders/jsv.js) and yields sparse boundary tensors."""
 
-    def __init__(self, data, threads=0, has_alpha=-1):
-        """has_alpha: for a GOP shard (no container header of its own), the whole stream's info.has_alpha."""
+    def __init__(self, data, threads=0, has_alpha=-1, scan_only=False):
+        """has_alpha: for a GOP shard (no container header of its own), the whole stream's info.has_alpha.
+        scan_only: leon_vlc_open_scan -- the bytes are read in place, only scan_picture() is served."""
         self.h = None
         self.lib = load()
-        self._bytes = bytes(data)
         h = C.c_void_p()
-        rc = self.lib.leon_vlc_open_shard(self._bytes, len(self._bytes), threads, has_alpha, C.byref(h))
+        if scan_only:
+            self._bytes = bytes(data) + bytes(16)
+            rc = self.lib.leon_vlc_open_scan(self._bytes, len(self._bytes) - 16, len(self._bytes), has_alpha, C.byref(h))
+        else:
+            self._bytes = bytes(data)
+            rc = self.lib.leon_vlc_open_shard(self._bytes, len(self._bytes), threads, has_alpha, C.byref(h))
         if rc != 0:
             raise VlcError(self.lib.leon_vlc_last_error().decode())
         self.h = h

@@ -266,6 +266,26 @@ def test_scan_picture_finds_what_the_parser_parses(name):
     assert n == len(whole)
 
 
+@pytest.mark.parametrize("name", ["ibbp_96x64", "slices5_ip_96x64", "yuva_ibbp_96x64"])
+def test_scan_stream_reads_in_place_what_a_copied_stream_reads(name):
+    """leon_vlc_open_scan (no copy, no read-ahead thread; the pipeline's gpu_parser mode opens every GOP shard with it):
+    the same scan results as a stream opened the ordinary way; the parsing calls are refused on it"""
+    data = read(name)
+    a, b = V.Stream(data, threads=1), V.Stream(data, scan_only=True)
+    assert (b.info.coded_width, b.info.coded_height, b.info.keymap_count) == (a.info.coded_width, a.info.coded_height, a.info.keymap_count)
+    n = 0
+    while True:
+        x, y = a.scan_picture(), b.scan_picture()
+        assert x == y
+        if x is None:
+            break
+        n += 1
+    assert n > 0
+    c = V.Stream(data, scan_only=True)
+    with pytest.raises(V.VlcError, match="scan_picture only"):
+        c.next_picture()
+
+
 def test_gpu_tables_are_the_parsers_tables():
     """leon_vlc_get_gpu_tables: every entry decodes back to a code of the right length; the 12-bit coefficient table
     agrees with the 16-bit one wherever it answers"""
