@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
+#include <deque>
 #include <cstdlib>
 #include <new>
 #include <string>
@@ -143,9 +144,15 @@ struct leon_decoder {
     int next_stage = 0;
     PicDesc* d_desc_ring = nullptr;   // kDescRing descriptors for ad-hoc submits
     PicDesc* h_desc_pinned = nullptr;
-    static constexpr int kDescRing = 65536;    // a wrap waits for the stream: rare enough with windows of a few thousand pictures
-    int desc_head = 0;
-    hipEvent_t desc_wrap_ev = nullptr;
+    // A lap of the ring is 65536 pictures; a range is reused only after the launches that read it have finished -- not by
+    // waiting for the STREAM at the wrap (the pipeline lost five windows' time, 45 ms, every 65536 pictures that way) but
+    // for the event recorded behind the last launch of that range, a lap ago: long since signalled.
+    static constexpr int kDescRing = 65536;
+    static constexpr int kDescEventEvery = 2048;       // descriptors per event
+    struct DescUse { int begin, end; hipEvent_t ev; };
+    std::deque<DescUse> desc_uses;                      // in the order they were recorded
+    std::vector<hipEvent_t> desc_ev_pool;
+    int desc_head = 0, desc_open_begin = 0, desc_open_end = 0;      // [open_begin, open_end): committed, no event behind it yet
     // rgba
     int32_t* d_slot_ids = nullptr;
     int32_t* h_slot_ids = nullptr;
@@ -412,17 +419,57 @@ void sorted_descs(const leon_decoder* d, const AnyPic* pics, int n, PicDesc* out
     for (int i = 0; i < n; i++) fill_desc(d, pics[i], out[at[class_of(pics[i].p)]++]);
 }
 
-// reserve n consecutive descriptors in the ring (wrap = wait for the previous lap)
+// an event behind everything committed so far
+int close_desc_range(leon_decoder* d)
+{
+    if (d->desc_open_end == d->desc_open_begin) return LEON_OK;
+    hipEvent_t ev = nullptr;
+    if (!d->desc_ev_pool.empty()) { ev = d->desc_ev_pool.back(); d->desc_ev_pool.pop_back(); }
+    else HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(ev, d->stream));
+    d->desc_uses.push_back(leon_decoder::DescUse{d->desc_open_begin, d->desc_open_end, ev});
+    d->desc_open_begin = d->desc_open_end;
+    return LEON_OK;
+}
+
+// reserve n consecutive descriptors in the ring; what lay there a lap ago must have been read
 int reserve_descs(leon_decoder* d, int n, int& at)
 {
     if (n > leon_decoder::kDescRing) return fail(LEON_ERR_INVALID, "batch of %d pictures exceeds %d; use leon_batch_create", n, leon_decoder::kDescRing);
-    if (d->desc_head + n > leon_decoder::kDescRing) {
-        HIP_TRY(hipStreamSynchronize(d->stream));
+    auto retire = [&](void) -> int {
+        leon_decoder::DescUse u = d->desc_uses.front();
+        d->desc_uses.pop_front();
+        HIP_TRY(hipEventSynchronize(u.ev));
+        d->desc_ev_pool.push_back(u.ev);
+        return LEON_OK;
+    };
+    if (d->desc_head + n > leon_decoder::kDescRing) {                 // wrap: the tail stays unused this lap
+        int rc = close_desc_range(d);
+        if (rc != LEON_OK) return rc;
+        while (d->desc_uses.size() > 1 && d->desc_uses.front().begin > d->desc_uses.back().begin)
+            if ((rc = retire()) != LEON_OK) return rc;               // ranges of the lap BEFORE this one, behind where it ended: the oldest there are
         d->desc_head = 0;
+        d->desc_open_begin = d->desc_open_end = 0;
     }
     at = d->desc_head;
+    if (d->desc_open_end > d->desc_open_begin && at < d->desc_open_end && at + n > d->desc_open_begin) {
+        const int rc = close_desc_range(d);
+        if (rc != LEON_OK) return rc;
+    }
+    while (!d->desc_uses.empty() && d->desc_uses.front().begin < at + n && d->desc_uses.front().end > at) {
+        const int rc = retire();
+        if (rc != LEON_OK) return rc;
+    }
     d->desc_head += n;
     return LEON_OK;
+}
+
+// the launches that read [at, at + n) have been queued
+int commit_descs(leon_decoder* d, int at, int n)
+{
+    if (d->desc_open_end == d->desc_open_begin) d->desc_open_begin = at;
+    d->desc_open_end = at + n;
+    return d->desc_open_end - d->desc_open_begin >= leon_decoder::kDescEventEvery ? close_desc_range(d) : LEON_OK;
 }
 
 }  // namespace
@@ -525,6 +572,8 @@ void leon_destroy(leon_decoder* d)
         hipEventDestroy(t.b);
     }
     for (auto e : d->ev_pool) hipEventDestroy(e);
+    for (auto& u : d->desc_uses) hipEventDestroy(u.ev);
+    for (auto e : d->desc_ev_pool) hipEventDestroy(e);
     for (auto& s : d->stages) {
         if (s.base) hipFree(s.base);
         if (s.host) hipHostFree(s.host);
@@ -663,6 +712,8 @@ int submit_picture_any(leon_decoder* d, const AnyPic& pic)
     }
     rc = launch_recon_type(d, type, d->d_desc_ring + at, 1, bytes, pic.sparse, pic.n_entries, pic.p.rgba_out != nullptr);
     if (rc != LEON_OK) return rc;
+    rc = commit_descs(d, at, 1);
+    if (rc != LEON_OK) return rc;
     HIP_TRY(hipEventRecord(s.done, d->stream));
     s.busy = true;
     return LEON_OK;
@@ -739,7 +790,9 @@ int submit_batch_any(leon_decoder* d, const AnyPic* pics, int n, int mem)
             bytes[class_of(pics[i].p)] += b;
         }
     HIP_TRY(hipMemcpyAsync(d->d_desc_ring + at, d->h_desc_pinned + at, sizeof(PicDesc) * n, hipMemcpyHostToDevice, d->stream));
-    return launch_recon(d, d->d_desc_ring + at, count, bytes, pics[0].sparse, entries);
+    rc = launch_recon(d, d->d_desc_ring + at, count, bytes, pics[0].sparse, entries);
+    if (rc != LEON_OK) return rc;
+    return commit_descs(d, at, n);
 }
 
 int batch_create_any(leon_decoder* d, const AnyPic* pics, int n, leon_batch** out)

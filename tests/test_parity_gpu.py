@@ -381,3 +381,43 @@ def test_overlapped_conversion_is_ordered_against_slot_reuse(L, O, S):
                 assert np.array_equal(got[i], O.ycbcr_to_rgba(*planes, cw, cw, ch, "cpu")), (rep, i)
     finally:
         dec.close()
+
+
+def test_descriptor_ring_wraps_without_draining_the_stream(L, O, S):
+    """Ad-hoc batches take their picture descriptors from a ring of 65536 (leon_hip.cpp reserve_descs); a range is reused
+    once the launches that read it a lap ago have finished (an event per 2048 descriptors) -- round 3 waited for the whole
+    stream at the wrap, which cost the pipeline five windows' time every 65536 pictures.  72 batches of 1000 pictures
+    queued without a sync in between (the ring wraps once), two contents alternating by batch: every slot must end up
+    with the content of the LAST batch that wrote it."""
+    import torch
+    cw = ch = 32
+    n = 1000
+    rng = np.random.default_rng(31)
+    tens = [S.make_picture(rng, cw, ch, S.PIC_I) for _ in range(2)]
+    dec = L.Decoder(cw, ch, n_slots=n)
+    try:
+        dev = [{k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in t.items() if isinstance(v, np.ndarray)} for t in tens]
+        torch.cuda.synchronize()
+
+        def batch(which):
+            d = dev[which]
+            return [L.make_picture(S.PIC_I, i, d["coef_y"].data_ptr(), d["coef_cb"].data_ptr(), d["coef_cr"].data_ptr(),
+                                   d["qscale"].data_ptr(), d["intra"].data_ptr(), device=True) for i in range(n)]
+        batches = [batch(0), batch(1)]
+        laps = 72
+        for k in range(laps):
+            dec.submit_batch(batches[k & 1], L.MEM_DEVICE)
+        dec.sync()
+        last = (laps - 1) & 1
+        t = tens[last]
+        exp = O.decode_picture(t["type"], cw, ch, t["coef_y"], t["coef_cb"], t["coef_cr"], t["qscale"], t["intra"])
+        for slot in (0, 1, 511, 999):
+            assert np.array_equal(planes_flat(*dec.read_planes(slot)), exp), slot
+        # and the ring goes on after the wrap
+        dec.submit_batch(batches[1 - last], L.MEM_DEVICE)
+        dec.sync()
+        t = tens[1 - last]
+        exp = O.decode_picture(t["type"], cw, ch, t["coef_y"], t["coef_cb"], t["coef_cr"], t["qscale"], t["intra"])
+        assert np.array_equal(planes_flat(*dec.read_planes(500)), exp)
+    finally:
+        dec.close()
