@@ -101,6 +101,7 @@ static constexpr int kLdsTile = 2 * kLdsHalf;
 static constexpr int kLdsQtab = 256;             // the first 64 dwords of Tables: both matrices and the premultiplier (192 B)
 static constexpr int kLdsSlots = 128;            // column pass: the ids of the live columns, one byte each
 static constexpr int kOffQtab = kLdsTile;
+static constexpr int kOffCarry = kOffQtab + 192;  // display kernels: the 64 bytes of the table strip no table uses hold the task's 8 + 8 vectors
 static constexpr int kOffSlots = kLdsTile + kLdsQtab;
 static constexpr int kLdsPerWave = kOffSlots + kLdsSlots;
 // fused display conversion: the Y rows of a half change lanes through a 512-byte park (it shares its place with the
@@ -652,7 +653,7 @@ __device__ __forceinline__ void display_half(const PicDesc& pd, const Geom& G, c
 // (., m) loads macroblock m's quantiser scale, flags and vectors as always and leaves them in `carry`); the luma and
 // alpha parts (2) take theirs from the lane of their macroblock by ds_bpermute -- no loads, no second wait for memory
 // in front of their reference fetches.  0: a task on its own loads what it needs.
-struct MbCarry { uint32_t mf, mk, flags; };       // raw vector words; q | intra << 8 | repadd >= 128 << 9 | direction << 10
+struct MbCarry { uint32_t flags; };       // q | intra << 8 | repadd >= 128 << 9 | direction << 10 (the vectors: LDS, kOffCarry)
 
 template <int TYPE, bool CHROMA, bool SPARSE, bool DISPLAY, int AMODE = 0, int CARRY = 0>
 __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int Rt, int g, char* lds, int lane, Display dsp, MbCarry& carry, bool alpha = false)
@@ -714,8 +715,10 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
         // this lane's macroblock is number 4 * side + (block >> 1) of the task: its chroma-part lane holds it
         const int src = (4 * dsp.side + (lo3 >> 1)) << 2;
         flags = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)carry.flags);
-        if (TYPE != 1) mf = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)carry.mf);
-        if (TYPE == 3) mk = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)carry.mk);
+        // the vectors wait in LDS (the 64 bytes behind the staged tables: kOffCarry) -- carried in registers like the
+        // flags, the three words went to scratch memory in the B kernel (12 bytes per lane: +6 % HBM traffic per launch)
+        if (TYPE != 1) mf = *reinterpret_cast<const uint32_t*>(lds + kOffCarry + src);
+        if (TYPE == 3) mk = *reinterpret_cast<const uint32_t*>(lds + kOffCarry + 32 + src);
     } else {
         flags = (uint32_t)(ldg<uint8_t>(gptr(pd.qscale), mb) & 31) | (ldg<uint8_t>(gptr(pd.intra), mb) != 0 ? 256u : 0u);   // I pictures honour the intra map too (COL_3)
         if (TYPE != 1) {
@@ -726,7 +729,11 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
             mk = ldg<uint32_t>(gptr(pd.mv_bwd), mb * 4);
             flags |= (uint32_t)(ldg<uint8_t>(gptr(pd.mb_dir), mb) & 3) << 10;
         }
-        if constexpr (CARRY == 1) carry = MbCarry{mf, mk, flags};
+        if constexpr (CARRY == 1) {       // lane i < 8 holds macroblock i of the task (and so does every lane i + 8 k)
+            carry.flags = flags;
+            if (TYPE != 1) *reinterpret_cast<uint32_t*>(lds + kOffCarry + ((lane & 7) << 2)) = mf;
+            if (TYPE == 3) *reinterpret_cast<uint32_t*>(lds + kOffCarry + 32 + ((lane & 7) << 2)) = mk;
+        }
     }
     const int q = (int)(flags & 31u);
     const bool ia = (flags & 256u) != 0u;

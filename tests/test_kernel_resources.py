@@ -17,10 +17,10 @@ HIPCC = "/opt/rocm/bin/hipcc"
 BUDGET = {
     "k_reconILi1ELb0E": 64, "k_reconILi2ELb0E": 64, "k_reconILi3ELb0E": 72,
     "k_reconILi1ELb1E": 64, "k_reconILi2ELb1E": 64, "k_reconILi3ELb1E": 72,
-    # the B display kernels are held to 7 waves: the macroblock maps carried from the chroma part to the luma parts cost
-    # two registers, which go to scratch (12 / 8 bytes per lane; measured -1 % per step against loading the maps three times)
-    "k_recon_displayILi1ELb0ELb0E": 64, "k_recon_displayILi2ELb0ELb0E": 64, "k_recon_displayILi3ELb0ELb0E": (72, 12),
-    "k_recon_displayILi1ELb1ELb0E": 64, "k_recon_displayILi2ELb1ELb0E": 64, "k_recon_displayILi3ELb1ELb0E": (72, 8),
+    # the B display kernels are held to 7 waves; the macroblock maps carried from the chroma part to the luma parts are one
+    # register (flags) -- the vectors wait in LDS: carried in registers they went to scratch (12 bytes per lane, +6 % traffic)
+    "k_recon_displayILi1ELb0ELb0E": 64, "k_recon_displayILi2ELb0ELb0E": 64, "k_recon_displayILi3ELb0ELb0E": 72,
+    "k_recon_displayILi1ELb1ELb0E": 64, "k_recon_displayILi2ELb1ELb0E": 64, "k_recon_displayILi3ELb1ELb0E": 72,
     # yuva (A part + Y part per side): one occupancy step below the three-component kernels
     "k_recon_displayILi1ELb0ELb1E": 64, "k_recon_displayILi2ELb0ELb1E": 72, "k_recon_displayILi3ELb0ELb1E": 88,
     "k_recon_displayILi1ELb1ELb1E": 64, "k_recon_displayILi2ELb1ELb1E": 72, "k_recon_displayILi3ELb1ELb1E": 88,
