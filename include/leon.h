@@ -232,6 +232,18 @@ int leon_timing_get(leon_decoder* d, int32_t kind, leon_kernel_stats* out);
  * (bench.py: the spread of a launch class, and the one-sided and the mixed B launches apart) */
 int leon_timing_get_launches(leon_decoder* d, leon_launch_time* out, int32_t cap, int32_t* n);
 
+/* Device memory the way the library allocates its own large buffers (slot ring, RGBA ring, arenas): physically
+ * CONTIGUOUS where the device has it (hipExtMallocWithFlags, hipDeviceMallocContiguous), an ordinary allocation otherwise.
+ * Why a caller should care: the reconstruction launches stream through many buffers at once, and the same launch on the
+ * same box took 0.39 ... 0.56 ms depending on which physical pages its RGBA frames had drawn -- an ordinary allocation
+ * is built from whatever fragments are free, and with small fragments the address translation of a launch that writes
+ * 7000 rows at a time misses (round 3, tools/probe/spread_probe.py, profiles/r03_launch_spread.json).  The boundary
+ * tensors and RGBA frames a caller hands to leon_submit_* may come from anywhere; these two calls are the allocator
+ * bench.py and the pipeline use.  (The reference's counterpart: gl.createTexture / texImage2D storage, jsv.js:51-87.)
+ * leon_device_malloc: *contiguous (may be NULL) = 1 when the contiguous request was granted. */
+int leon_device_malloc(int32_t device_id, size_t bytes, void** ptr, int32_t* contiguous);
+int leon_device_free(void* ptr);
+
 /* measured device copy bandwidth (GB/s) over `bytes` with a streaming float4
  * copy kernel: the "measured HBM roofline" of BASELINE.md section 2 */
 int leon_measure_copy_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, double* gbps);

@@ -419,6 +419,26 @@ void sorted_descs(const leon_decoder* d, const AnyPic* pics, int n, PicDesc* out
     for (int i = 0; i < n; i++) fill_desc(d, pics[i], out[at[class_of(pics[i].p)]++]);
 }
 
+// Large buffers: physically contiguous when the device grants it (include/leon.h leon_device_malloc).  Which kinds of
+// buffer ask for it: LEON_CONTIGUOUS = a mask of kBig* (A/B runs); the default is what round 3 measured, one box, runs
+// alternating: bench.py 6.05-6.10 ms per step with slots + caller's buffers contiguous against 5.92-6.29 without; the
+// pipeline 176 k pictures/s with slots + RGBA ring, 169 k with nothing, 150-155 k with the ARENAS contiguous as well
+// (the parser's slabs: stream bytes in, records and lists out -- slower, reproducibly; not understood).
+enum { kBigSlots = 1, kBigRgbaRing = 2, kBigArenas = 4, kBigCaller = 8 };
+hipError_t big_alloc(void** ptr, size_t bytes, int kind, bool* contiguous = nullptr)
+{
+    static const int mask = getenv("LEON_CONTIGUOUS") ? atoi(getenv("LEON_CONTIGUOUS")) : (kBigSlots | kBigRgbaRing | kBigCaller);
+    if (contiguous) *contiguous = false;
+    if ((mask & kind) && bytes >= ((size_t)1 << 20)) {
+        if (hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocContiguous) == hipSuccess) {
+            if (contiguous) *contiguous = true;
+            return hipSuccess;
+        }
+        (void)hipGetLastError();
+    }
+    return hipMalloc(ptr, bytes);
+}
+
 // an event behind everything committed so far
 int close_desc_range(leon_decoder* d)
 {
@@ -542,7 +562,7 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
         leon_destroy(d);
         return fail(LEON_ERR_NOMEM, "%s", msg.c_str());
     };
-    if (hipMalloc(&d->d_slots, d->slot_stride * (size_t)cfg->n_slots + 256) != hipSuccess) return bail("slot ring");
+    if (big_alloc((void**)&d->d_slots, d->slot_stride * (size_t)cfg->n_slots + 256, kBigSlots) != hipSuccess) return bail("slot ring");
     if (hipMemsetAsync(d->d_slots, 0, d->slot_stride * (size_t)cfg->n_slots + 256, d->stream) != hipSuccess) return bail("slot memset");
     if (hipMalloc(&d->d_tables, sizeof(Tables)) != hipSuccess) return bail("tables");
     memcpy(d->qm, kDefaultIntra, 64);
@@ -1147,14 +1167,34 @@ int leon_timing_get_launches(leon_decoder* d, leon_launch_time* out, int32_t cap
     return LEON_OK;
 }
 
+int leon_device_malloc(int32_t device_id, size_t bytes, void** ptr, int32_t* contiguous)
+{
+    if (!ptr || bytes == 0) return fail(LEON_ERR_INVALID, "null pointer or zero bytes");
+    *ptr = nullptr;
+    HIP_TRY(hipSetDevice(device_id));
+    bool c = false;
+    if (big_alloc(ptr, bytes, kBigCaller, &c) != hipSuccess) {
+        (void)hipGetLastError();
+        return fail(LEON_ERR_NOMEM, "device allocation of %zu bytes failed", bytes);
+    }
+    if (contiguous) *contiguous = c ? 1 : 0;
+    return LEON_OK;
+}
+
+int leon_device_free(void* ptr)
+{
+    if (ptr) HIP_TRY(hipFree(ptr));
+    return LEON_OK;
+}
+
 int leon_measure_copy_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, double* gbps)
 {
     if (!d || !gbps || bytes < 4096 || iters < 1) return fail(LEON_ERR_INVALID, "bad argument");
     HIP_TRY(hipSetDevice(d->dev));
     bytes &= ~(size_t)4095;
     uint4 *src = nullptr, *dst = nullptr;
-    if (hipMalloc(&src, bytes) != hipSuccess) return fail(LEON_ERR_NOMEM, "copy source");
-    if (hipMalloc(&dst, bytes) != hipSuccess) {
+    if (big_alloc((void**)&src, bytes, kBigCaller) != hipSuccess) return fail(LEON_ERR_NOMEM, "copy source");      // allocated like the buffers it is the yardstick for
+    if (big_alloc((void**)&dst, bytes, kBigCaller) != hipSuccess) {
         hipFree(src);
         return fail(LEON_ERR_NOMEM, "copy destination");
     }

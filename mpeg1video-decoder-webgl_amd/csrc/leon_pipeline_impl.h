@@ -157,7 +157,7 @@ bool arena_reserve(leon_pipeline* p, Arena* a, size_t host_need, size_t dev_need
     if (dev_need > a->cap) {
         const size_t cap = std::max(dev_need + dev_need / 2, (size_t)8 << 20);
         char* dv = nullptr;
-        if (hipMalloc((void**)&dv, cap) != hipSuccess) return false;
+        if (big_alloc((void**)&dv, cap, kBigArenas) != hipSuccess) return false;
         if (a->dev && a->dev_owned) hipFree(a->dev);        // only ever grown while the arena is being filled: nothing in flight reads it
         a->dev = dv;
         a->cap = cap;
@@ -944,7 +944,7 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
     };
     if (rc != LEON_OK) { leon_pipeline_destroy(p); return rc; }
     if (hipStreamCreateWithFlags(&p->copy_stream, hipStreamNonBlocking) != hipSuccess) return bail(LEON_ERR_HIP, "copy stream");
-    if (hipMalloc((void**)&p->d_rgba, (size_t)p->R * p->W * p->max_pics * p->frame_bytes) != hipSuccess) {
+    if (big_alloc((void**)&p->d_rgba, (size_t)p->R * p->W * p->max_pics * p->frame_bytes, kBigRgbaRing) != hipSuccess) {
         const std::string what = "RGBA ring of " + std::to_string((size_t)p->R * p->W * p->max_pics * p->frame_bytes >> 20) + " MiB (windows_in_flight " +
                                  std::to_string(p->R) + " x gops_per_window " + std::to_string(p->W) + " x max_gop_pictures " + std::to_string(p->max_pics) +
                                  " x " + std::to_string(p->frame_bytes) + " bytes per frame)";
@@ -1065,7 +1065,7 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
         const size_t dev_each = (pad256(largest + 16) + 48 * largest + (size_t)p->max_pics * per_pic + 65535) / 65536 * 65536;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)n_arenas * dev_each < free_b / 2 && !getenv("LEON_DEBUG_NO_SLABS")) {
-            if (hipMalloc((void**)&p->slab_dev, (size_t)n_arenas * dev_each) == hipSuccess &&
+            if (big_alloc((void**)&p->slab_dev, (size_t)n_arenas * dev_each, kBigArenas) == hipSuccess &&
                 hipHostMalloc((void**)&p->slab_host, (size_t)n_arenas * host_each, hipHostMallocDefault) == hipSuccess) {
                 for (int i = 0; i < n_arenas; i++) {
                     Arena* a = p->all_arenas[(size_t)i];

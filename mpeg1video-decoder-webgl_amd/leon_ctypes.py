@@ -27,7 +27,7 @@ SYMBOLS = [
     "leon_convert_rgba", "leon_convert_rgba_batch", "leon_read_planes", "leon_write_planes",
     "leon_read_alpha_plane", "leon_write_alpha_plane", "leon_slot_device_ptr", "leon_sync", "leon_set_overlap_convert", "leon_timing_enable", "leon_timing_reset", "leon_timing_get",
     "leon_timing_get_launches",
-    "leon_measure_copy_bandwidth",
+    "leon_measure_copy_bandwidth", "leon_device_malloc", "leon_device_free",
 ]
 # include/leon_pipeline.h (same library)
 PIPELINE_SYMBOLS = [
@@ -158,6 +158,8 @@ def load():
     lib.leon_timing_get.argtypes = [C.c_void_p, C.c_int32, C.POINTER(KernelStats)]
     lib.leon_timing_get_launches.argtypes = [C.c_void_p, C.POINTER(LaunchTime), C.c_int32, C.POINTER(C.c_int32)]
     lib.leon_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double)]
+    lib.leon_device_malloc.argtypes = [C.c_int32, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
+    lib.leon_device_free.argtypes = [C.c_void_p]
     lib.leon_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.c_void_p, C.c_size_t, PIPELINE_CB, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.leon_pipeline_create_partial.argtypes = [C.POINTER(PipelineConfig), C.c_void_p, C.c_size_t, C.c_size_t, PIPELINE_CB, C.c_void_p, C.POINTER(C.c_void_p)]
     lib.leon_pipeline_feed.argtypes = [C.c_void_p, C.c_size_t]
@@ -481,5 +483,52 @@ class Pipeline:
     def __del__(self):
         try:
             self.close()
+        except Exception:
+            pass
+
+
+class DeviceBuffer:
+    """leon_device_malloc / leon_device_free: device memory allocated the way the library allocates its own large buffers
+    (physically contiguous where the device grants it).  `ptr` is the device address; `contiguous` says which it got.
+    as_tensor(dtype, shape) wraps (a part of) it as a torch tensor without copying -- the buffer must outlive the tensor
+    (the tensor keeps a reference to it)."""
+
+    def __init__(self, nbytes, device_id=0):
+        self.lib = load()
+        p, c = C.c_void_p(), C.c_int32(0)
+        _chk(self.lib.leon_device_malloc(device_id, nbytes, C.byref(p), C.byref(c)))
+        self.ptr, self.nbytes, self.contiguous, self.device_id = p.value, nbytes, bool(c.value), device_id
+
+    def as_tensor(self, dtype, shape, offset=0):
+        import numpy as np
+        import torch
+        n = int(np.prod(shape))
+        item = torch.empty(0, dtype=dtype).element_size()
+        if offset < 0 or offset + n * item > self.nbytes:
+            raise ValueError("tensor does not fit in the buffer")
+        owner = self
+
+        class _Iface:          # __cuda_array_interface__: torch.as_tensor wraps the memory and keeps `self` alive
+            pass
+        o = _Iface()
+        o.owner = owner
+        typestr = {1: "|u1", 2: "<i2", 4: "<i4", 8: "<i8"}[item] if dtype not in (torch.float32, torch.float64) else ("<f4" if dtype == torch.float32 else "<f8")
+        if dtype == torch.uint8:
+            typestr = "|u1"
+        elif dtype == torch.int8:
+            typestr = "|i1"
+        elif dtype == torch.int16:
+            typestr = "<i2"
+        o.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (self.ptr + offset, False), "version": 2}
+        return torch.as_tensor(o, device="cuda:%d" % self.device_id)
+
+    def free(self):
+        if self.ptr:
+            _chk(self.lib.leon_device_free(self.ptr))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
         except Exception:
             pass

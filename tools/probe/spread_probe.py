@@ -26,6 +26,10 @@ def main():
     ap.add_argument("--pictures", type=int, default=128)
     ap.add_argument("--launches", type=int, default=12)
     ap.add_argument("--realloc-only", type=int, default=0, help="only N rounds of: free everything, allocate again, time the launch")
+    ap.add_argument("--contig", type=int, default=0, help="with --hold: this many more RGBA buffers from hipExtMallocWithFlags(hipDeviceMallocContiguous)")
+    ap.add_argument("--lib-alloc", action="store_true", help="RGBA frames and coefficient planes from leon_device_malloc (contiguous unless LEON_CONTIGUOUS=0) instead of torch")
+    ap.add_argument("--junk-gb", type=float, default=0.0, help="allocate (and keep) this much device memory before anything else")
+    ap.add_argument("--hold", type=int, default=0, help="N RGBA buffers (and N sets of coefficient planes) alive at once: every combination of the first three timed")
     a = ap.parse_args()
     import torch
     import leon_ctypes as L
@@ -33,18 +37,39 @@ def main():
     n = a.pictures
     rng = np.random.default_rng(0x4C454F4E)
     t = S.make_picture(rng, CW, CH, S.PIC_I)
+    junk = torch.empty(int(a.junk_gb * (1 << 30)), dtype=torch.uint8, device="cuda") if a.junk_gb > 0 else None
     stream = torch.cuda.Stream()
     dec = L.Decoder(CW, CH, FW, FH, n_slots=n, device_id=0, stream=stream.cuda_stream)
     dec.measure_copy_bandwidth(1 << 30, 40)
     copy = dec.measure_copy_bandwidth(1 << 31, 5)
     keys = ("coef_y", "coef_cb", "coef_cr", "qscale", "intra")
 
+    held = []
+
     def upload():
-        return [{k: torch.from_numpy(np.ascontiguousarray(t[k])).cuda() for k in keys} for _ in range(n)]
+        if not a.lib_alloc:
+            return [{k: torch.from_numpy(np.ascontiguousarray(t[k])).cuda() for k in keys} for _ in range(n)]
+        per = sum((t[k].nbytes + 255) // 256 * 256 for k in keys)
+        big = L.DeviceBuffer(n * per)
+        held.append(big)
+        res = []
+        for i in range(n):
+            o, d = i * per, {}
+            for k in keys:
+                src = np.ascontiguousarray(t[k])
+                d[k] = big.as_tensor({np.dtype("int16"): torch.int16, np.dtype("uint8"): torch.uint8}[src.dtype], src.shape, o)
+                d[k].copy_(torch.from_numpy(src))
+                o += (src.nbytes + 255) // 256 * 256
+            res.append(d)
+        return res
 
     frame_bytes = FW * FH * 4
 
     def frames(stride, shift=0):
+        if a.lib_alloc:
+            buf = L.DeviceBuffer(n * stride + shift + 4096)
+            base = (buf.ptr + 4095) // 4096 * 4096 + shift
+            return buf, [base + i * stride for i in range(n)]
         buf = torch.empty(n * stride + shift + 4096, dtype=torch.uint8, device="cuda")
         base = (buf.data_ptr() + 4095) // 4096 * 4096 + shift
         return buf, [base + i * stride for i in range(n)]
@@ -65,7 +90,7 @@ def main():
         dec.batch_destroy(b)
         return {"min": round(ms[0], 4), "median": round(ms[len(ms) // 2], 4), "max": round(ms[-1], 4)}
 
-    out = {"pictures": n, "copy_gbps": copy, "runs": [], "lib": os.environ.get("LEON_DEBUG_LIB", "tree")}
+    out = {"pictures": n, "copy_gbps": copy, "runs": [], "lib": os.environ.get("LEON_DEBUG_LIB", "tree"), "junk_gb": a.junk_gb, "lib_alloc": a.lib_alloc, "LEON_CONTIGUOUS": os.environ.get("LEON_CONTIGUOUS", "default")}
     if a.realloc_only:
         ms = []
         for rep in range(a.realloc_only):
@@ -76,6 +101,26 @@ def main():
             torch.cuda.empty_cache()
         out["medians_ms"] = ms
         out["min"], out["mean"], out["max"] = min(ms), sum(ms) / len(ms), max(ms)
+        print(json.dumps(out))
+        return
+    if a.hold:
+        # placements side by side: is a slow one slow whatever it is paired with?
+        bufs = [frames(frame_bytes) for _ in range(a.hold)]
+        sets = [upload() for _ in range(min(a.hold, 3))]
+        out["rgba_x_coef_median_ms"] = [[run(t_, ptrs_)["median"] for t_ in sets] for _, ptrs_ in bufs]
+        out["rgba_base"] = [hex(ptrs_[0]) for _, ptrs_ in bufs]
+        if a.contig:
+            import ctypes as C
+            hip = C.CDLL("libamdhip64.so")
+            hip.hipExtMallocWithFlags.argtypes = [C.POINTER(C.c_void_p), C.c_size_t, C.c_uint]
+            out["contiguous_median_ms"], out["contiguous_rc"] = [], []
+            for _ in range(a.contig):
+                ptr = C.c_void_p()
+                rc = hip.hipExtMallocWithFlags(C.byref(ptr), n * frame_bytes + 4096, 0x4)      # hipDeviceMallocContiguous
+                out["contiguous_rc"].append(rc)
+                if rc == 0:
+                    base = (ptr.value + 4095) // 4096 * 4096
+                    out["contiguous_median_ms"].append([run(t_, [base + i * frame_bytes for i in range(n)])["median"] for t_ in sets[:2]])
         print(json.dumps(out))
         return
     tensors = upload()
