@@ -240,7 +240,8 @@ int leon_timing_get_launches(leon_decoder* d, leon_launch_time* out, int32_t cap
  * 7000 rows at a time misses (round 3, tools/probe/spread_probe.py, profiles/r03_launch_spread.json).  The boundary
  * tensors and RGBA frames a caller hands to leon_submit_* may come from anywhere; these two calls are the allocator
  * bench.py and the pipeline use.  (The reference's counterpart: gl.createTexture / texImage2D storage, jsv.js:51-87.)
- * leon_device_malloc: *contiguous (may be NULL) = 1 when the contiguous request was granted. */
+ * leon_device_malloc: on device `device_id` (which becomes the calling thread's current device); *contiguous (may be
+ * NULL) = 1 when the contiguous request was granted.  leon_device_free(NULL) is a no-op. */
 int leon_device_malloc(int32_t device_id, size_t bytes, void** ptr, int32_t* contiguous);
 int leon_device_free(void* ptr);
 
