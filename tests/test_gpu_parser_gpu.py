@@ -121,3 +121,18 @@ def test_random_corruption_never_hangs_or_faults(L):
         finally:
             pipe.close()
     assert refused > 0
+
+
+def test_a_picture_whose_group_counters_need_more_than_64_kb_of_lds(L):
+    """k_vlc_index counts a picture's groups in dynamic LDS, four bytes each: 3584 x 2048 has 21504 groups = 86 KB, beyond
+    what a launch gets without hipFuncAttributeMaxDynamicSharedMemorySize (the pipeline asks for it at create).  One
+    I B B P B B GOP, GPU-parsed frames against the host-parsed pipeline, and the I and P picture against the oracle."""
+    data = ibbp_stream(3584, 2048, [6], seed=77)
+    gpu, order, stats = run_pipeline(L, data, parser_threads=1, gops_per_window=1, gpu_parser=True)
+    host, _, _ = run_pipeline(L, data, parser_threads=1, gops_per_window=1)
+    assert stats["pictures"] == 6 and sorted(gpu) == sorted(host) == [(0, d) for d in range(6)]
+    for k in sorted(gpu):
+        assert np.array_equal(gpu[k], host[k]), k
+    want = oracle_frames(data)
+    for k in ((0, 2), (0, 5), (0, 3)):
+        assert np.array_equal(gpu[k].reshape(-1), np.asarray(want[k]).reshape(-1)), k
