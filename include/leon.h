@@ -236,8 +236,8 @@ int leon_timing_get_launches(leon_decoder* d, leon_launch_time* out, int32_t cap
  * CONTIGUOUS where the device has it (hipExtMallocWithFlags, hipDeviceMallocContiguous), an ordinary allocation otherwise.
  * Why a caller should care: the reconstruction launches stream through many buffers at once, and the same launch on the
  * same box took 0.39 ... 0.56 ms depending on which physical pages its RGBA frames had drawn -- an ordinary allocation
- * is built from whatever fragments are free, and with small fragments the address translation of a launch that writes
- * 7000 rows at a time misses (round 3, tools/probe/spread_probe.py, profiles/r03_launch_spread.json).  The boundary
+ * is built from whatever fragments are free; with contiguous memory the runs of one box agree to better than 1 %
+ * (round 3, tools/probe/spread_probe.py, profiles/r03_launch_spread.json; the mechanism is not established).  The boundary
  * tensors and RGBA frames a caller hands to leon_submit_* may come from anywhere; these two calls are the allocator
  * bench.py and the pipeline use.  (The reference's counterpart: gl.createTexture / texImage2D storage, jsv.js:51-87.)
  * leon_device_malloc: on device `device_id` (which becomes the calling thread's current device); *contiguous (may be
