@@ -41,6 +41,9 @@ typedef uint32_t vlc_u4 __attribute__((ext_vector_type(4)));      // a 16-byte r
 #ifndef LEON_VLC_WAVES
 #define LEON_VLC_WAVES 4
 #endif
+#ifndef LEON_VLC_TWO_STEPS
+#define LEON_VLC_TWO_STEPS 1
+#endif
 #ifndef LEON_VLC_MULTI_BITS
 #define LEON_VLC_MULTI_BITS 12
 #endif
@@ -310,14 +313,27 @@ __device__ __forceinline__ int vlc_block(VlcWin& r, const VlcLds& L, const VlcGe
     for (;;) {
         VLC_SYNC(r, c);
         r.fill();
-        const uint32_t m = L.multi12[(uint32_t)(r.w >> (64 - kVlcMultiBits))];
-        const int used = (int)(m & 15u);
+        uint32_t m = L.multi12[(uint32_t)(r.w >> (64 - kVlcMultiBits))];
+        int used = (int)(m & 15u);
         if (used) {
             r.drop(used);
             k += (int)((m >> 4) & 7u);
             n += (int)(m >> 8);                              // every symbol: its run, and the position it fills
             if (n > 64) return VLC_ERR_INDEX;                // = the last symbol's position past 63 (the earlier ones lie below it)
             if (m & 0x80u) break;                            // end of block
+#if LEON_VLC_TWO_STEPS
+            // a second step on the bits that are left: fill() left 33 or more, the first step took 12 at most, the
+            // lookup wants 12.  What it cannot answer (an escape, a long code) waits for the top of the loop.
+            m = L.multi12[(uint32_t)(r.w >> (64 - kVlcMultiBits))];
+            used = (int)(m & 15u);
+            if (used) {
+                r.drop(used);
+                k += (int)((m >> 4) & 7u);
+                n += (int)(m >> 8);
+                if (n > 64) return VLC_ERR_INDEX;
+                if (m & 0x80u) break;
+            }
+#endif
         } else {
             // one symbol: an escape ('0000 01', 20 or 28 bits) or a code of 12 .. 16 bits (seven zeros in front; a
             // second table in LDS)
