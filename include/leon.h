@@ -76,7 +76,12 @@ typedef struct leon_config {
                               plane and never decodes it (IDCT_GL loops over three components, jsv.js:1223): A is
                               reconstructed like luma here -- same maps, luma vectors, same matrices.  Needs an even
                               frame width. */
-    int32_t reserved;
+    int32_t contiguous_slots; /* 1: ask for a physically contiguous slot ring (leon_device_malloc explains what that buys: the
+                              launches that read references run at their fast end, bench.py asks for it).  0, the default:
+                              an ordinary allocation -- in a process that creates and destroys many decoders, later
+                              pipelines produced wrong B pictures in 13 of 30 runs of the GPU test suite with contiguous
+                              slot rings and in none of 17 without (round 3, not understood: leon_hip.cpp big_alloc);
+                              a decoder that lives as long as its process is the case it is meant for.  (Was `reserved`.) */
 } leon_config;
 
 typedef struct leon_picture {

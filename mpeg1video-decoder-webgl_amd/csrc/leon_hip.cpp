@@ -419,24 +419,35 @@ void sorted_descs(const leon_decoder* d, const AnyPic* pics, int n, PicDesc* out
     for (int i = 0; i < n; i++) fill_desc(d, pics[i], out[at[class_of(pics[i].p)]++]);
 }
 
-// Large buffers: physically contiguous when the device grants it (include/leon.h leon_device_malloc).  Which kinds of
-// buffer ask for it: LEON_CONTIGUOUS = a mask of kBig* (A/B runs); the default is what round 3 measured, one box, runs
-// alternating: bench.py 6.05-6.10 ms per step with slots + caller's buffers contiguous against 5.92-6.29 without; the
-// pipeline 176 k pictures/s with slots + RGBA ring, 169 k with nothing, 150-155 k with the ARENAS contiguous as well
-// (the parser's slabs: stream bytes in, records and lists out -- slower, reproducibly; not understood).
+// Large buffers: physically contiguous when the device grants it (include/leon.h leon_device_malloc) -- by default ONLY
+// what a caller asks for through leon_device_malloc.  Which kinds of buffer ask for it: LEON_CONTIGUOUS = a mask of kBig*
+// (A/B runs).  What round 3 measured, one box, runs alternating: bench.py 6.05-6.10 ms per step with the caller's buffers
+// (and the slot ring) contiguous against 5.92-6.29 without; the pipeline 176 k pictures/s with slot ring + RGBA ring
+// contiguous, 169 k with nothing, 150-155 k with the parser's arenas contiguous as well.
+// Why the library's own rings do NOT use it all the same: with the SLOT RING contiguous, 45 % of the runs of the whole
+// GPU test suite in one process (13 of 30; none of 17 without it) ended with a B picture of a LATER, small pipeline wrong
+// in whole macroblocks -- the same wrong picture every time -- although that pipeline's own buffers are far too small to
+// be contiguous: the decoders before it had allocated and freed 40-180 MB contiguous slot rings.  Serialising every stage
+// on the host, zero-filling the rings, poisoning the arenas, one parser stream, the host parser instead of the GPU's:
+// none of them changes it; not allocating slot rings contiguously does.  Not understood (tools/probe/partial_stress.py
+// does not reproduce it outside the suite); until it is, memory that kernels both write and read, allocated and freed over
+// a process's life, stays ordinary.
 enum { kBigSlots = 1, kBigRgbaRing = 2, kBigArenas = 4, kBigCaller = 8 };
-hipError_t big_alloc(void** ptr, size_t bytes, int kind, bool* contiguous = nullptr)
+hipError_t big_alloc(void** ptr, size_t bytes, int kind, bool* contiguous = nullptr, bool asked = false)
 {
-    static const int mask = getenv("LEON_CONTIGUOUS") ? atoi(getenv("LEON_CONTIGUOUS")) : (kBigSlots | kBigRgbaRing | kBigCaller);
+    static const int mask = getenv("LEON_CONTIGUOUS") ? atoi(getenv("LEON_CONTIGUOUS")) : kBigCaller;
+    // LEON_DEBUG_ZERO_ALLOC = a mask of kBig*: such buffers start as zeros (hunting reads of memory nobody wrote)
+    static const int zero = getenv("LEON_DEBUG_ZERO_ALLOC") ? atoi(getenv("LEON_DEBUG_ZERO_ALLOC")) : 0;
     if (contiguous) *contiguous = false;
-    if ((mask & kind) && bytes >= ((size_t)1 << 20)) {
-        if (hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocContiguous) == hipSuccess) {
-            if (contiguous) *contiguous = true;
-            return hipSuccess;
-        }
-        (void)hipGetLastError();
+    hipError_t e = hipErrorOutOfMemory;
+    if (((mask & kind) || asked) && bytes >= ((size_t)1 << 20)) {
+        e = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocContiguous);
+        if (e == hipSuccess) { if (contiguous) *contiguous = true; }
+        else (void)hipGetLastError();
     }
-    return hipMalloc(ptr, bytes);
+    if (e != hipSuccess) e = hipMalloc(ptr, bytes);
+    if (e == hipSuccess && (zero & kind)) { (void)hipMemset(*ptr, 0, bytes); (void)hipDeviceSynchronize(); }
+    return e;
 }
 
 // an event behind everything committed so far
@@ -562,7 +573,7 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
         leon_destroy(d);
         return fail(LEON_ERR_NOMEM, "%s", msg.c_str());
     };
-    if (big_alloc((void**)&d->d_slots, d->slot_stride * (size_t)cfg->n_slots + 256, kBigSlots) != hipSuccess) return bail("slot ring");
+    if (big_alloc((void**)&d->d_slots, d->slot_stride * (size_t)cfg->n_slots + 256, kBigSlots, nullptr, cfg->contiguous_slots == 1) != hipSuccess) return bail("slot ring");
     if (hipMemsetAsync(d->d_slots, 0, d->slot_stride * (size_t)cfg->n_slots + 256, d->stream) != hipSuccess) return bail("slot memset");
     if (hipMalloc(&d->d_tables, sizeof(Tables)) != hipSuccess) return bail("tables");
     memcpy(d->qm, kDefaultIntra, 64);

@@ -538,6 +538,11 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
         GopJob* job = w->jobs[j];
         // upload the GOP's arena; everything of this window is copied before its first launch
         const size_t up = p->gpu_parser ? job->upload_bytes : job->arena->used;
+        // LEON_DEBUG_POISON=1: everything of the arena that the kernels are expected to write before they read it starts
+        // as 0xCD bytes -- a read of something nobody wrote then shows in every run, not only when the memory's history
+        // happens to differ from zero
+        static const bool poison = getenv("LEON_DEBUG_POISON") && atoi(getenv("LEON_DEBUG_POISON")) == 1;
+        if (poison && p->gpu_parser && job->arena->used > up) HIP_TRY(hipMemsetAsync(job->arena->dev + up, 0xCD, job->arena->used - up, p->copy_stream));
         if (up) {
             HIP_TRY(hipMemcpyAsync(job->arena->dev, job->arena->host, up, hipMemcpyHostToDevice, p->copy_stream));
             p->st_upload += up;
@@ -586,12 +591,17 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
     hipEvent_t copied = get_event(d);
     if (!copied) return LEON_ERR_HIP;
     HIP_TRY(hipEventRecord(copied, p->copy_stream));
+    // LEON_DEBUG_SERIAL=1: the host waits behind every stage (uploads, parser kernels, reconstruction) -- takes every
+    // cross-stream dependency out of the picture when a wrong frame is being hunted
+    static const bool serial = getenv("LEON_DEBUG_SERIAL") && atoi(getenv("LEON_DEBUG_SERIAL")) == 1;
+    if (serial) HIP_TRY(hipStreamSynchronize(p->copy_stream));
     if (p->gpu_parser) {
         // upload -> parser kernels (their own stream) -> reconstruction (the decoder's stream)
         HIP_TRY(hipStreamWaitEvent(p->vlc_stream[vlc_stream_of(w->id)], copied, 0));
         d->ev_pool.push_back(copied);
         const int rc = launch_gpu_parser(p, w);
         if (rc != LEON_OK) return rc;
+        if (serial) HIP_TRY(hipStreamSynchronize(p->vlc_stream[vlc_stream_of(w->id)]));
         hipEvent_t parsed = get_event(d);
         if (!parsed) return LEON_ERR_HIP;
         HIP_TRY(hipEventRecord(parsed, p->vlc_stream[vlc_stream_of(w->id)]));
@@ -635,6 +645,7 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
                 if (rc != LEON_OK) return rc;
             }
     }
+    if (serial) HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(hipEventRecord(w->done, d->stream));
     // frames in display order, GOP-major
     const double rate = p->vinfo.picture_rate > 0 ? p->vinfo.picture_rate : 25.0;

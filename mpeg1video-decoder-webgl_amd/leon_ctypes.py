@@ -45,7 +45,7 @@ class LeonError(RuntimeError):
 class Config(C.Structure):
     _fields_ = [("coded_width", C.c_int32), ("coded_height", C.c_int32), ("frame_width", C.c_int32),
                 ("frame_height", C.c_int32), ("n_slots", C.c_int32), ("device_id", C.c_int32),
-                ("stream", C.c_void_p), ("alpha", C.c_int32), ("reserved", C.c_int32)]
+                ("stream", C.c_void_p), ("alpha", C.c_int32), ("contiguous_slots", C.c_int32)]
 
 
 class Picture(C.Structure):
@@ -250,9 +250,10 @@ def make_sparse_picture(ptype, out_slot, grp_off, entries, n_entries, qscale, in
 class Decoder:
     """Thin object wrapper over the C ABI; method names follow include/leon.h."""
 
-    def __init__(self, coded_w, coded_h, frame_w=None, frame_h=None, n_slots=13, device_id=0, stream=None, alpha=False):
+    def __init__(self, coded_w, coded_h, frame_w=None, frame_h=None, n_slots=13, device_id=0, stream=None, alpha=False, contiguous_slots=False):
         self.lib = load()
-        cfg = Config(coded_w, coded_h, frame_w or coded_w, frame_h or coded_h, n_slots, device_id, stream, 1 if alpha else 0, 0)
+        cfg = Config(coded_w, coded_h, frame_w or coded_w, frame_h or coded_h, n_slots, device_id, stream, 1 if alpha else 0,
+                     1 if contiguous_slots else 0)
         h = C.c_void_p()
         _chk(self.lib.leon_create(C.byref(cfg), C.byref(h)))
         self.h = h

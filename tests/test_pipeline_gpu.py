@@ -56,6 +56,18 @@ def oracle_frames(data):
     return out
 
 
+def differing_macroblocks(a, b):
+    """[(macroblock row, column, differing pixels)] of two RGBA frames -- for assertion messages"""
+    a, b = np.asarray(a), np.asarray(b)
+    if a.shape != b.shape or a.ndim != 3:
+        return "shapes %s / %s" % (a.shape, b.shape)
+    d = np.any(a != b, axis=2)
+    out = {}
+    for y, x in zip(*np.nonzero(d)):
+        out[(int(y) // 16, int(x) // 16)] = out.get((int(y) // 16, int(x) // 16), 0) + 1
+    return sorted((r, c, n) for (r, c), n in out.items())
+
+
 def run_pipeline(L, data, **kw):
     kw.setdefault("gpu_parser", False)          # the library's default is the GPU parser: tests/test_gpu_parser_gpu.py asks for it by name
     got = {}
@@ -236,7 +248,7 @@ def test_a_stream_that_is_still_arriving(L, gpu_parser):
         pipe.close()
     assert set(got) == set(want)
     for k in want:
-        assert np.array_equal(got[k], want[k]), k
+        assert np.array_equal(got[k], want[k]), (k, differing_macroblocks(got[k], want[k]))
     # feeding backwards or beyond the end is refused / ignored
     with pytest.raises(L.LeonError):
         L.Pipeline(data, valid_bytes=len(data) + 1)
