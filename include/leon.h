@@ -80,7 +80,7 @@ typedef struct leon_config {
                               launches that read references run at their fast end, bench.py asks for it).  0, the default:
                               an ordinary allocation -- in a process that creates and destroys many decoders, later
                               pipelines produced wrong B pictures in 13 of 30 runs of the GPU test suite with contiguous
-                              slot rings and in none of 17 without (round 3, not understood: leon_hip.cpp big_alloc);
+                              slot rings and in none of 22 without (round 3, not understood: leon_hip.cpp big_alloc);
                               a decoder that lives as long as its process is the case it is meant for.  (Was `reserved`.) */
 } leon_config;
 
@@ -237,14 +237,15 @@ int leon_timing_get(leon_decoder* d, int32_t kind, leon_kernel_stats* out);
  * (bench.py: the spread of a launch class, and the one-sided and the mixed B launches apart) */
 int leon_timing_get_launches(leon_decoder* d, leon_launch_time* out, int32_t cap, int32_t* n);
 
-/* Device memory the way the library allocates its own large buffers (slot ring, RGBA ring, arenas): physically
- * CONTIGUOUS where the device has it (hipExtMallocWithFlags, hipDeviceMallocContiguous), an ordinary allocation otherwise.
+/* Device memory for a caller's large, long-lived buffers: physically CONTIGUOUS where the device has it
+ * (hipExtMallocWithFlags, hipDeviceMallocContiguous), an ordinary allocation otherwise.
  * Why a caller should care: the reconstruction launches stream through many buffers at once, and the same launch on the
  * same box took 0.39 ... 0.56 ms depending on which physical pages its RGBA frames had drawn -- an ordinary allocation
  * is built from whatever fragments are free; with contiguous memory the runs of one box agree to better than 1 %
  * (round 3, tools/probe/spread_probe.py, profiles/r03_launch_spread.json; the mechanism is not established).  The boundary
- * tensors and RGBA frames a caller hands to leon_submit_* may come from anywhere; these two calls are the allocator
- * bench.py and the pipeline use.  (The reference's counterpart: gl.createTexture / texImage2D storage, jsv.js:51-87.)
+ * tensors and RGBA frames a caller hands to leon_submit_* may come from anywhere; bench.py takes them from here (and
+ * sets leon_config.contiguous_slots).  The library's own rings are ordinary allocations -- see contiguous_slots for why.
+ * (The reference's counterpart: gl.createTexture / texImage2D storage, jsv.js:51-87.)
  * leon_device_malloc: on device `device_id` (which becomes the calling thread's current device); *contiguous (may be
  * NULL) = 1 when the contiguous request was granted.  leon_device_free(NULL) is a no-op. */
 int leon_device_malloc(int32_t device_id, size_t bytes, void** ptr, int32_t* contiguous);

@@ -425,7 +425,7 @@ void sorted_descs(const leon_decoder* d, const AnyPic* pics, int n, PicDesc* out
 // (and the slot ring) contiguous against 5.92-6.29 without; the pipeline 176 k pictures/s with slot ring + RGBA ring
 // contiguous, 169 k with nothing, 150-155 k with the parser's arenas contiguous as well.
 // Why the library's own rings do NOT use it all the same: with the SLOT RING contiguous, 45 % of the runs of the whole
-// GPU test suite in one process (13 of 30; none of 17 without it) ended with a B picture of a LATER, small pipeline wrong
+// GPU test suite in one process (13 of 30; none of 22 without it) ended with a B picture of a LATER, small pipeline wrong
 // in whole macroblocks -- the same wrong picture every time -- although that pipeline's own buffers are far too small to
 // be contiguous: the decoders before it had allocated and freed 40-180 MB contiguous slot rings.  Serialising every stage
 // on the host, zero-filling the rings, poisoning the arenas, one parser stream, the host parser instead of the GPU's:
