@@ -61,7 +61,7 @@ def main():
         "upload_gb": s["upload_bytes"] / 1e9, "upload_gbps": s["upload_bytes"] / 1e9 / s["seconds"],
         "entries_per_picture": s["entries"] / max(1, s["pictures"]), "stream_bytes": s["stream_bytes"],
         "stream_megabit_per_picture": s["stream_bytes"] * 8 / 1e6 / (12 * a.gops), "host_threads": os.cpu_count(),
-        "stream": "%d different GOPs, looped %d times" % (a.gops, a.loop), "slice_order": os.environ.get("LEON_VLC_ORDER", "row")}))
+        "stream": "%d different GOPs, looped %d times" % (a.gops, a.loop)}))
 
 
 if __name__ == "__main__":
