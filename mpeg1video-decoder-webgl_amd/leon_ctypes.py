@@ -503,25 +503,18 @@ class DeviceBuffer:
     def as_tensor(self, dtype, shape, offset=0):
         import numpy as np
         import torch
-        n = int(np.prod(shape))
-        item = torch.empty(0, dtype=dtype).element_size()
-        if offset < 0 or offset + n * item > self.nbytes:
+        typestr = {torch.uint8: "|u1", torch.int8: "|i1", torch.int16: "<i2", torch.int32: "<i4", torch.int64: "<i8",
+                   torch.float32: "<f4", torch.float64: "<f8"}[dtype]
+        n = int(np.prod(shape)) * int(typestr[2:])
+        if offset < 0 or offset + n > self.nbytes:
             raise ValueError("tensor does not fit in the buffer")
-        owner = self
 
-        class _Iface:          # __cuda_array_interface__: torch.as_tensor wraps the memory and keeps `self` alive
+        class _View:          # __cuda_array_interface__: torch.as_tensor wraps the memory and keeps this object (and the buffer) alive
             pass
-        o = _Iface()
-        o.owner = owner
-        typestr = {1: "|u1", 2: "<i2", 4: "<i4", 8: "<i8"}[item] if dtype not in (torch.float32, torch.float64) else ("<f4" if dtype == torch.float32 else "<f8")
-        if dtype == torch.uint8:
-            typestr = "|u1"
-        elif dtype == torch.int8:
-            typestr = "|i1"
-        elif dtype == torch.int16:
-            typestr = "<i2"
-        o.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (self.ptr + offset, False), "version": 2}
-        return torch.as_tensor(o, device="cuda:%d" % self.device_id)
+        v = _View()
+        v.owner = self
+        v.__cuda_array_interface__ = {"shape": tuple(int(x) for x in shape), "typestr": typestr, "data": (self.ptr + offset, False), "version": 2}
+        return torch.as_tensor(v, device="cuda:%d" % self.device_id)
 
     def free(self):
         if self.ptr:
