@@ -1,5 +1,7 @@
 """GPU: leon_device_malloc / leon_device_free (include/leon.h) -- the allocator bench.py and the pipeline use for their
-large buffers (physically contiguous where the device grants it) -- through the ctypes wrapper L.DeviceBuffer."""
+large buffers (physically contiguous where the device grants it) -- through the ctypes wrapper L.DeviceBuffer.
+(Named to run last: freed contiguous memory in a process's history is what round 3 saw go with wrong frames in later
+pipelines -- DESIGN.md section 4, "spread" -- and nothing suggests a caller's 8 MB do that, but the suite need not find out.)"""
 import numpy as np
 import pytest
 
