@@ -64,6 +64,33 @@ def test_same_frames_as_the_host_front_end_at_1080p(L):
         assert bad.size == 0, "frame %s: %d pixels differ from the oracle, rows %d..%d" % (k, len(bad), bad[:, 0].min(), bad[:, 0].max())
 
 
+def test_sixteen_different_1080p_gops_same_frames_from_both_front_ends(L):
+    """the stream the end-to-end figures are quoted on (tools/stream_1080p.py ensure_varied: 16 closed IBBP GOPs of different
+    content, quantiser scales 2 .. 31 by row, 192 pictures): every frame of the GPU-parsed pipeline equals the host-parsed
+    one (SHA-256 per frame; the two-GOP stream above is the one checked against the oracle)"""
+    import hashlib
+    import stream_1080p
+    data = stream_1080p.load_varied()
+
+    def digests(gpu_parser):
+        out = {}
+
+        def on_window(window, frames):
+            for f in frames:
+                out[(f["gop"], f["display_index"])] = hashlib.sha256(L.read_frame(f).tobytes()).hexdigest()
+        pipe = L.Pipeline(data, parser_threads=8, gops_per_window=8, gpu_parser=gpu_parser, on_window=on_window)
+        try:
+            pipe.wait()
+            assert pipe.ended and pipe.error is None
+        finally:
+            pipe.close()
+        return out
+    gpu, host = digests(True), digests(False)
+    assert len(gpu) == 16 * 12 and sorted(gpu) == sorted(host)
+    bad = [k for k in sorted(gpu) if gpu[k] != host[k]]
+    assert not bad, bad[:8]
+
+
 def test_damaged_streams_are_refused(L):
     """bytes of one GOP overwritten: the run ends with an error instead of delivering garbage -- whichever layer
     notices (the host's picture layer, or a slice on the GPU when its window completes)"""
