@@ -597,7 +597,10 @@ void leon_destroy(leon_decoder* d)
 {
     if (!d) return;
     hipSetDevice(d->dev);
+    // nothing of this decoder may still run when its memory goes: both streams, explicitly (hipFree's own wait for the
+    // device is not something to lean on -- and not promised for memory from hipExtMallocWithFlags)
     if (d->stream) hipStreamSynchronize(d->stream);
+    if (d->conv_stream) hipStreamSynchronize(d->conv_stream);
     for (auto& t : d->timed) {
         hipEventDestroy(t.a);
         hipEventDestroy(t.b);
@@ -618,7 +621,6 @@ void leon_destroy(leon_decoder* d)
     if (d->h_slot_ids) hipHostFree(d->h_slot_ids);
     if (d->d_rgba_tmp) hipFree(d->d_rgba_tmp);
     if (d->conv_stream) {
-        hipStreamSynchronize(d->conv_stream);
         hipStreamDestroy(d->conv_stream);
         hipEventDestroy(d->ev_recon_done);
         hipEventDestroy(d->ev_conv_done);

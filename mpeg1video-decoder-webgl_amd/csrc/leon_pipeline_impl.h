@@ -1171,6 +1171,11 @@ void leon_pipeline_destroy(leon_pipeline* p)
     if (p->submitter.joinable()) p->submitter.join();
     if (p->notifier.joinable()) p->notifier.join();      // drains what was submitted, releasing instead of delivering
     hipSetDevice(p->cfg.device_id);
+    // every stream of the pipeline is idle before any of its memory is freed (a submit interrupted by `stop` may have
+    // left uploads or parser kernels behind that no window's event covers)
+    if (p->copy_stream) hipStreamSynchronize(p->copy_stream);
+    for (hipStream_t vs : p->vlc_stream)
+        if (vs) hipStreamSynchronize(vs);
     if (p->dec) leon_sync(p->dec);
     {
         std::lock_guard<std::mutex> lk(p->mu);
