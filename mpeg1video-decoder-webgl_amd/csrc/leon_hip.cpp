@@ -613,7 +613,8 @@ void leon_destroy(leon_decoder* d)
         if (s.host) hipHostFree(s.host);
         if (s.done) hipEventDestroy(s.done);
     }
-    if (d->d_slots) hipFree(d->d_slots);
+    // LEON_DEBUG_LEAK_SLOTS=1 (hunting the contiguous-ring flake): the slot ring is never freed
+    if (d->d_slots && !(getenv("LEON_DEBUG_LEAK_SLOTS") && atoi(getenv("LEON_DEBUG_LEAK_SLOTS")) == 1)) hipFree(d->d_slots);
     if (d->d_tables) hipFree(d->d_tables);
     if (d->d_desc_ring) hipFree(d->d_desc_ring);
     if (d->h_desc_pinned) hipHostFree(d->h_desc_pinned);
