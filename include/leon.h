@@ -36,7 +36,9 @@
 extern "C" {
 #endif
 
-#define LEON_ABI_VERSION 2
+/* 3 (round 4): leon_config.reserved became contiguous_slots, leon_pipeline_config.gpu_parser 0 now means the GPU parser
+ * (leon_pipeline.h), leon_device_pool_stats, leon_measure_stream_bandwidth; leon_vlc.h carries a version of its own. */
+#define LEON_ABI_VERSION 3
 
 enum {
     LEON_OK = 0,
@@ -78,10 +80,13 @@ typedef struct leon_config {
                               frame width. */
     int32_t contiguous_slots; /* 1: ask for a physically contiguous slot ring (leon_device_malloc explains what that buys: the
                               launches that read references run at their fast end, bench.py asks for it).  0, the default:
-                              an ordinary allocation -- in a process that creates and destroys many decoders, later
-                              pipelines produced wrong B pictures in 13 of 30 runs of the GPU test suite with contiguous
-                              slot rings and in none of 22 without (round 3, not understood: leon_hip.cpp big_alloc);
-                              a decoder that lives as long as its process is the case it is meant for.  (Was `reserved`.) */
+                              an ordinary allocation.  A contiguous ring is taken from, and at leon_destroy returned to, a
+                              pool that lives as long as the process: contiguous memory is never handed back to the driver
+                              (round 3 saw wrong B pictures in LATER pipelines of processes that had hipFree'd contiguous
+                              rings -- 13 of 30 whole-suite runs, none when the rings were never freed; leon_hip.cpp
+                              big_alloc).  So the knob is safe in a process that creates and destroys many decoders; what
+                              it costs is that the process keeps the high-water mark of its contiguous requests
+                              (leon_device_pool_stats).  (Was `reserved` in ABI 2.) */
 } leon_config;
 
 typedef struct leon_picture {
@@ -106,7 +111,11 @@ typedef struct leon_picture {
      * picture nobody predicts from (B pictures); out_slot is then ignored (-1 is accepted). */
     void*   rgba_out;
     int32_t no_planes;
-    int32_t reserved;
+    int32_t qm_set;        /* ABI 3 (was `reserved`, 0): which of the decoder's quantiser-matrix sets the picture is dequantised
+                              with -- 0 = the matrices of leon_set_quant_matrices, > 0 = a set from leon_add_quant_matrices.
+                              The reference reloads both matrices at every sequence header (decoders/jsv.js:540-558); a
+                              batch of pictures from different sequences (the pipeline's windows of GOP shards) names one
+                              set per picture. */
     const int16_t* coef_a; /* yuva decoders (leon_config.alpha): the A plane's raw levels, coded-luma size; else NULL */
 } leon_picture;
 
@@ -129,7 +138,7 @@ typedef struct leon_sparse_picture {
     const uint8_t* mb_dir;
     void*   rgba_out;          /* fused display conversion, as in leon_picture */
     int32_t no_planes;
-    int32_t reserved2;
+    int32_t qm_set;            /* as in leon_picture (was `reserved2`) */
 } leon_sparse_picture;
 
 typedef struct leon_kernel_stats {
@@ -166,6 +175,12 @@ void leon_destroy(leon_decoder* d);
 /* = the QUANT_MATRIX re-uploads on a sequence header (decoders/jsv.js:540-558).
  *   64 bytes each, natural (de-zig-zagged) order; NULL keeps the current one. */
 int leon_set_quant_matrices(leon_decoder* d, const uint8_t* intra64, const uint8_t* non_intra64);
+/* ABI 3.  The same for a caller that decodes pictures of SEVERAL sequences in one batch (the pipeline: every key-map GOP
+ *   starts with a sequence header of its own, and the reference reloads the matrices at each, jsv.js:540-558): registers
+ *   a further set of matrices beside set 0 (what leon_set_quant_matrices writes) and returns its id in *set, the same id
+ *   for the same matrices; pictures name their set in leon_picture.qm_set.  NULL = the default matrix (jsv.js:1777-1806).
+ *   A set never changes once registered; at most 255 per decoder.  Asynchronous: ordered by the decoder's stream. */
+int leon_add_quant_matrices(leon_decoder* d, const uint8_t* intra64, const uint8_t* non_intra64, int32_t* set);
 
 /* = jsv.prototype.setRenderBuffer (decoders/jsv.js:1165-1176): first free slot, marked in use */
 int leon_acquire_slot(leon_decoder* d, int32_t* slot);
@@ -244,16 +259,27 @@ int leon_timing_get_launches(leon_decoder* d, leon_launch_time* out, int32_t cap
  * is built from whatever fragments are free; with contiguous memory the runs of one box agree to better than 1 %
  * (round 3, tools/probe/spread_probe.py, profiles/r03_launch_spread.json; the mechanism is not established).  The boundary
  * tensors and RGBA frames a caller hands to leon_submit_* may come from anywhere; bench.py takes them from here (and
- * sets leon_config.contiguous_slots).  The library's own rings are ordinary allocations -- see contiguous_slots for why.
+ * sets leon_config.contiguous_slots).  The library's own rings are ordinary allocations unless asked (contiguous_slots).
  * (The reference's counterpart: gl.createTexture / texImage2D storage, jsv.js:51-87.)
  * leon_device_malloc: on device `device_id` (which becomes the calling thread's current device); *contiguous (may be
- * NULL) = 1 when the contiguous request was granted.  leon_device_free(NULL) is a no-op. */
+ * NULL) = 1 when the contiguous request was granted.  Requests of 1 MiB and more are rounded up to 2 MiB granules.
+ * leon_device_free: waits for the device like hipFree, then hands a contiguous buffer to the process's POOL -- the next
+ * contiguous request of that device reuses it; it is never returned to the driver (see contiguous_slots) -- and frees
+ * an ordinary one.  leon_device_free(NULL) is a no-op.
+ * leon_device_pool_stats: bytes of contiguous memory this process has taken from the driver (all devices), how many of
+ * them are handed out right now, and in how many driver allocations; any pointer may be NULL. */
 int leon_device_malloc(int32_t device_id, size_t bytes, void** ptr, int32_t* contiguous);
 int leon_device_free(void* ptr);
+int leon_device_pool_stats(uint64_t* held_bytes, uint64_t* in_use_bytes, int32_t* segments);
 
 /* measured device copy bandwidth (GB/s) over `bytes` with a streaming float4
  * copy kernel: the "measured HBM roofline" of BASELINE.md section 2 */
 int leon_measure_copy_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, double* gbps);
+/* The same 16-byte-per-lane shape with `reads` source streams and `writes` destination streams of `bytes` each (0..2 and
+ * 0..2, not both 0): (0,1) = what the memory system takes when a launch only writes, (1,2) a launch that writes twice what
+ * it reads -- the fused I and P launches write 55-65 % of their bytes, and a 1:1 copy says little about how close they are
+ * to their wall.  *gbps counts every stream's bytes.  Buffers as in leon_measure_copy_bandwidth (the caller's allocator). */
+int leon_measure_stream_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, int32_t reads, int32_t writes, double* gbps);
 
 #ifdef __cplusplus
 }

@@ -16,8 +16,10 @@
  * (mpeg1video-decoder-webgl_amd/napi/leon_napi.cc), the MI355X-side of the reference's 'frame' event
  * (decoders/jsv.js:673).
  *
- * Requirements on the stream: JSV with a key map (or a raw elementary stream: one shard), closed GOPs,
- * frame_width % 8 == 0 (fused display conversion).
+ * Requirements on the stream: JSV with a key map (or a raw elementary stream: one shard), closed GOPs, ONE picture size
+ * (a sequence header that changes the size ends the run with an error; one that changes the quantiser matrices -- the
+ * reference reloads them at every header, decoders/jsv.js:540-558 -- is honoured per picture, round 4).  Any frame width:
+ * widths that are no multiple of 8 take an unfused road inside (planes + one conversion launch per picture).
  */
 #ifndef LEON_PIPELINE_H
 #define LEON_PIPELINE_H
@@ -55,6 +57,9 @@ typedef struct leon_pipeline_config {
      *   LEON_PIPELINE_PARSER_DEFAULT (0) and LEON_PIPELINE_PARSER_GPU (1): on the GPU, one lane per slice
      *     (csrc/leon_vlc_gpu.h); the parser threads only read the picture layer and upload the stream bytes.  Errors of
      *     a slice surface when its window completes.  The default since round 3: six times the host front end.
+     *     A stream beyond the GPU parser's limits (a picture of more than ~40 k block groups -- larger than 4096 x 2304 --,
+     *     a GOP shard of 2^28 bytes) is decoded on the parser threads under DEFAULT and refused under an explicit GPU
+     *     (leon_pipeline_info.gpu_parser says which it is).
      *   LEON_PIPELINE_PARSER_HOST (-1): on the parser threads (libleon_vlc.so).
      * Same frames either way. */
     int32_t gpu_parser;
@@ -87,6 +92,8 @@ typedef struct leon_pipeline_info {
     uint32_t shard_gops;        /* how many of them this pipeline decodes (per pass over the stream) */
     uint32_t first_gop;         /* key-map entry the run starts with (start_seconds) */
     int32_t parser_threads, gops_per_window;
+    int32_t gpu_parser;         /* 1: the slice layer is decoded on the GPU, 0: on the parser threads (what LEON_PIPELINE_PARSER_DEFAULT chose) */
+    int32_t reserved;
 } leon_pipeline_info;
 
 typedef struct leon_pipeline_stats {

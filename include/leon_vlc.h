@@ -41,6 +41,11 @@
 extern "C" {
 #endif
 
+/* 2 (round 4; the header had no version before): leon_vlc_picture has open_gop, leon_vlc_picture_scan has end_byte /
+ * open_gop / reserved -- a binding compiled against an older header would hand the library structs that are too small.
+ * Bindings check leon_vlc_abi_version() == LEON_VLC_ABI_VERSION at load. */
+#define LEON_VLC_ABI_VERSION 2
+
 enum {
     LEON_VLC_OK = 0,
     LEON_VLC_END = 0,            /* leon_vlc_next_picture: end of stream */
@@ -85,6 +90,7 @@ typedef struct leon_vlc_picture {
                                      front of the GOP's second anchor may predict from the GOP before it */
 } leon_vlc_picture;
 
+int leon_vlc_abi_version(void);
 const char* leon_vlc_last_error(void);
 
 /* Copies `n` bytes of a JSV stream (container header + key map, decoders/jsv.js:237-313) or of a

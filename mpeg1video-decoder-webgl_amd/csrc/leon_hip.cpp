@@ -7,11 +7,13 @@
 
 #include <hip/hip_runtime.h>
 #include <algorithm>
+#include <array>
 #include <cstdarg>
 #include <cstdio>
 #include <cstring>
 #include <deque>
 #include <cstdlib>
+#include <mutex>
 #include <new>
 #include <string>
 #include <vector>
@@ -88,7 +90,7 @@ AnyPic any_of(const leon_sparse_picture& q)
     a.p.type = q.type; a.p.out_slot = q.out_slot; a.p.ref_fwd_slot = q.ref_fwd_slot; a.p.ref_bwd_slot = q.ref_bwd_slot;
     a.p.qscale = q.qscale; a.p.intra = q.intra; a.p.repadd = q.repadd;
     a.p.mv_fwd = q.mv_fwd; a.p.mv_bwd = q.mv_bwd; a.p.mb_dir = q.mb_dir;
-    a.p.rgba_out = q.rgba_out; a.p.no_planes = q.no_planes;
+    a.p.rgba_out = q.rgba_out; a.p.no_planes = q.no_planes; a.p.qm_set = q.qm_set;
     a.grp_off = q.grp_off; a.entries = q.entries; a.n_entries = q.n_entries;
     a.sparse = true;
     return a;
@@ -135,8 +137,14 @@ struct leon_decoder {
     std::vector<int32_t> writer_of;
     uint32_t epoch = 0;
     Tables h_tables{};
-    Tables* d_tables = nullptr;
+    Tables* d_tables = nullptr;       // matrix set 0 (leon_set_quant_matrices) + the conversion tables
     uint8_t qm[128];
+    // matrix sets 1 .. kMaxQSets - 1 (leon_add_quant_matrices): the sequences of a stream whose headers carry other
+    // matrices than the first (decoders/jsv.js:540-558); a picture names its set (leon_picture.qm_set)
+    static constexpr int kMaxQSets = 256;
+    QTables* d_qsets = nullptr;       // [kMaxQSets], entry 0 unused
+    QTables* h_qsets = nullptr;       // pinned mirror: the source of the asynchronous uploads stays valid
+    std::vector<std::array<uint8_t, 128>> qsets;      // [0] unused; the matrices of set i, for the lookup
     // host-submit staging ring
     static constexpr int kStages = 4;
     Staging stages[kStages];
@@ -198,14 +206,20 @@ int get_event_pair(leon_decoder* d, hipEvent_t& a, hipEvent_t& b)
     return LEON_OK;
 }
 
-void upload_tables(leon_decoder* d)
+void fill_qtables(QTables& q, const uint8_t* qm128)
 {
+    memset(&q, 0, sizeof q);
     for (int c = 0; c < 8; c++)
         for (int i = 0; i < 8; i++) {
-            d->h_tables.qmT[0][c][i] = d->qm[i * 8 + c];
-            d->h_tables.qmT[1][c][i] = d->qm[64 + i * 8 + c];
-            d->h_tables.pmT[c][i] = kPremultiplier[i * 8 + c];
+            q.qmT[0][c][i] = qm128[i * 8 + c];
+            q.qmT[1][c][i] = qm128[64 + i * 8 + c];
+            q.pmT[c][i] = kPremultiplier[i * 8 + c];
         }
+}
+
+void upload_tables(leon_decoder* d)
+{
+    fill_qtables(d->h_tables.q, d->qm);
     static_assert(LEON_RGBA_LUT_SHIFT == kLutShift && sizeof(kLeonRgbaLut) == sizeof(d->h_tables.rgba_lut), "leon_rgba_lut.h and leon_kernels.h disagree");
     memcpy(d->h_tables.rgba_lut, kLeonRgbaLut, sizeof(kLeonRgbaLut));
 }
@@ -269,6 +283,8 @@ int check_pic(const leon_decoder* d, const AnyPic& a)
         if (!p.mv_bwd || !p.mb_dir) return fail(LEON_ERR_INVALID, "B picture without mv_bwd/mb_dir");
         if (writes_planes && p.ref_bwd_slot == p.out_slot) return fail(LEON_ERR_INVALID, "out_slot equals ref_bwd_slot");
     }
+    if (p.qm_set < 0 || p.qm_set > (int32_t)d->qsets.size() - 1 + (d->qsets.empty() ? 1 : 0))
+        return fail(LEON_ERR_INVALID, "qm_set %d: the decoder has %zu matrix sets beside set 0 (leon_add_quant_matrices)", p.qm_set, d->qsets.empty() ? (size_t)0 : d->qsets.size() - 1);
     if (p.rgba_out) {
         if (d->cfg.frame_width & 7) return fail(LEON_ERR_INVALID, "fused display conversion needs frame_width %% 8 == 0 (it is %d)", d->cfg.frame_width);
         if ((size_t)p.rgba_out & 15) return fail(LEON_ERR_INVALID, "rgba_out must be 16-byte aligned");
@@ -299,6 +315,7 @@ void fill_desc(const leon_decoder* d, const AnyPic& a, PicDesc& o)
     o.rgba = (uint8_t*)p.rgba_out;
     o.no_planes = p.rgba_out ? p.no_planes : 0;
     o.pad_ = 0;
+    o.qt = p.qm_set > 0 ? d->d_qsets + p.qm_set : &d->d_tables->q;
 }
 
 // a submit that overwrites a slot still being converted on the second stream waits for it
@@ -420,19 +437,93 @@ void sorted_descs(const leon_decoder* d, const AnyPic* pics, int n, PicDesc* out
 }
 
 // Large buffers: physically contiguous when the device grants it (include/leon.h leon_device_malloc) -- by default ONLY
-// what a caller asks for through leon_device_malloc.  Which kinds of buffer ask for it: LEON_CONTIGUOUS = a mask of kBig*
-// (A/B runs).  What round 3 measured, one box, runs alternating: bench.py 6.05-6.10 ms per step with the caller's buffers
-// (and the slot ring) contiguous against 5.92-6.29 without; the pipeline 176 k pictures/s with slot ring + RGBA ring
-// contiguous, 169 k with nothing, 150-155 k with the parser's arenas contiguous as well.
-// Why the library's own rings do NOT use it all the same: with the SLOT RING contiguous, 45 % of the runs of the whole
-// GPU test suite in one process (13 of 30; none of 22 without it) ended with a B picture of a LATER, small pipeline wrong
-// in whole macroblocks -- the same wrong picture every time -- although that pipeline's own buffers are far too small to
-// be contiguous: the decoders before it had allocated and freed 40-180 MB contiguous slot rings.  Serialising every stage
-// on the host, zero-filling the rings, poisoning the arenas, one parser stream, the host parser instead of the GPU's:
-// none of them changes it; not allocating slot rings contiguously does.  Not understood (tools/probe/partial_stress.py
-// does not reproduce it outside the suite); until it is, memory that kernels both write and read, allocated and freed over
-// a process's life, stays ordinary.
+// what a caller asks for through leon_device_malloc / leon_config.contiguous_slots.  Which of the library's own kinds of
+// buffer ask for it too: LEON_CONTIGUOUS = a mask of kBig* (A/B runs).  What round 3 measured, one box, runs alternating:
+// bench.py 6.05-6.10 ms per step with the caller's buffers (and the slot ring) contiguous against 5.92-6.29 without; the
+// pipeline 176 k pictures/s with slot ring + RGBA ring contiguous, 169 k with nothing, 150-155 k with the parser's arenas
+// contiguous as well.
+//
+// CONTIGUOUS MEMORY IS NEVER RETURNED TO THE DRIVER (round 4).  Round 3: with contiguous slot rings that were hipFree'd when
+// their decoder went, 13 of 30 runs of the whole GPU test suite in one process ended with a B picture of a LATER, small
+// pipeline wrong in whole macroblocks (the same picture every time; none of 22 runs with ordinary rings, none of 6 with
+// contiguous rings that were simply never freed).  The victim's own buffers are ordinary allocations, every stream of the
+// earlier decoder was idle before its ring was freed, and every byte the B kernels read is written by this library first
+// (walked again in round 4: descriptors, tables, lists, maps, slots, LDS) -- what the failing runs share is not a read of
+// this library but the driver getting physically contiguous pages back in mid-process.  So it does not get them back:
+// a contiguous allocation becomes a SEGMENT of a process-lifetime pool, big_free() hands its range to the next request
+// (first the smallest free range that fits; ranges are split at 2 MiB granules and merged with free neighbours of their
+// segment), and only ordinary allocations go through hipFree.  What that costs: a process holds the high-water mark of its
+// contiguous requests until it exits (leon_device_pool_stats reports it).
 enum { kBigSlots = 1, kBigRgbaRing = 2, kBigArenas = 4, kBigCaller = 8 };
+
+struct ContigPool {
+    struct Range { char* ptr; size_t bytes; int dev; int seg; bool free; };
+    std::mutex mu;
+    std::vector<Range> ranges;      // ordered by (segment, address): neighbours in the vector are neighbours in memory
+    int n_segments = 0;
+    size_t held = 0, in_use = 0;    // bytes taken from the driver / handed out
+    static constexpr size_t kGranule = (size_t)2 << 20;
+
+    // a free range of the device that fits, the smallest one; nullptr: none
+    void* take(size_t need, int dev)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        size_t best = (size_t)-1;
+        for (size_t i = 0; i < ranges.size(); i++)
+            if (ranges[i].free && ranges[i].dev == dev && ranges[i].bytes >= need && (best == (size_t)-1 || ranges[i].bytes < ranges[best].bytes)) best = i;
+        if (best == (size_t)-1) return nullptr;
+        if (ranges[best].bytes > need) {       // split: the tail stays free
+            Range tail = ranges[best];
+            tail.ptr += need;
+            tail.bytes -= need;
+            ranges[best].bytes = need;
+            ranges.insert(ranges.begin() + (long)best + 1, tail);
+        }
+        ranges[best].free = false;
+        in_use += need;
+        return ranges[best].ptr;
+    }
+    void add_segment(void* p, size_t bytes, int dev)      // a fresh contiguous allocation, handed out whole
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        ranges.push_back(Range{(char*)p, bytes, dev, n_segments++, false});
+        held += bytes;
+        in_use += bytes;
+    }
+    int device_of(const void* p)          // of a range that is handed out, -1: not ours
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (const Range& r : ranges)
+            if (r.ptr == (const char*)p && !r.free) return r.dev;
+        return -1;
+    }
+    // true: p was one of ours and is free again (merged with free neighbours of its segment)
+    bool give_back(void* p)
+    {
+        std::lock_guard<std::mutex> lk(mu);
+        for (size_t i = 0; i < ranges.size(); i++) {
+            if (ranges[i].ptr != (char*)p || ranges[i].free) continue;
+            ranges[i].free = true;
+            in_use -= ranges[i].bytes;
+            if (i + 1 < ranges.size() && ranges[i + 1].free && ranges[i + 1].seg == ranges[i].seg) {
+                ranges[i].bytes += ranges[i + 1].bytes;
+                ranges.erase(ranges.begin() + (long)i + 1);
+            }
+            if (i > 0 && ranges[i - 1].free && ranges[i - 1].seg == ranges[i].seg) {
+                ranges[i - 1].bytes += ranges[i].bytes;
+                ranges.erase(ranges.begin() + (long)i);
+            }
+            return true;
+        }
+        return false;
+    }
+};
+ContigPool& contig_pool()
+{
+    static ContigPool* pool = new ContigPool();       // never destroyed: its memory lives as long as the process
+    return *pool;
+}
+
 hipError_t big_alloc(void** ptr, size_t bytes, int kind, bool* contiguous = nullptr, bool asked = false)
 {
     static const int mask = getenv("LEON_CONTIGUOUS") ? atoi(getenv("LEON_CONTIGUOUS")) : kBigCaller;
@@ -441,13 +532,31 @@ hipError_t big_alloc(void** ptr, size_t bytes, int kind, bool* contiguous = null
     if (contiguous) *contiguous = false;
     hipError_t e = hipErrorOutOfMemory;
     if (((mask & kind) || asked) && bytes >= ((size_t)1 << 20)) {
-        e = hipExtMallocWithFlags(ptr, bytes, hipDeviceMallocContiguous);
-        if (e == hipSuccess) { if (contiguous) *contiguous = true; }
-        else (void)hipGetLastError();
+        int dev = 0;
+        (void)hipGetDevice(&dev);
+        const size_t need = (bytes + ContigPool::kGranule - 1) / ContigPool::kGranule * ContigPool::kGranule;
+        if (void* p = contig_pool().take(need, dev)) {
+            *ptr = p;
+            e = hipSuccess;
+        } else {
+            e = hipExtMallocWithFlags(ptr, need, hipDeviceMallocContiguous);
+            if (e == hipSuccess) contig_pool().add_segment(*ptr, need, dev);
+            else (void)hipGetLastError();
+        }
+        if (e == hipSuccess && contiguous) *contiguous = true;
     }
     if (e != hipSuccess) e = hipMalloc(ptr, bytes);
     if (e == hipSuccess && (zero & kind)) { (void)hipMemset(*ptr, 0, bytes); (void)hipDeviceSynchronize(); }
     return e;
+}
+
+// The counterpart of big_alloc.  The caller has made sure nothing in flight touches the buffer (every stream that used it
+// is idle): a pooled range goes straight to the next request, and hipFree's own wait for the device is not leaned on.
+hipError_t big_free(void* p)
+{
+    if (!p) return hipSuccess;
+    if (contig_pool().give_back(p)) return hipSuccess;
+    return hipFree(p);
 }
 
 // an event behind everything committed so far
@@ -613,9 +722,10 @@ void leon_destroy(leon_decoder* d)
         if (s.host) hipHostFree(s.host);
         if (s.done) hipEventDestroy(s.done);
     }
-    // LEON_DEBUG_LEAK_SLOTS=1 (hunting the contiguous-ring flake): the slot ring is never freed
-    if (d->d_slots && !(getenv("LEON_DEBUG_LEAK_SLOTS") && atoi(getenv("LEON_DEBUG_LEAK_SLOTS")) == 1)) hipFree(d->d_slots);
+    if (d->d_slots) big_free(d->d_slots);          // a contiguous ring goes back to the process's pool, never to the driver (big_alloc)
     if (d->d_tables) hipFree(d->d_tables);
+    if (d->d_qsets) hipFree(d->d_qsets);
+    if (d->h_qsets) hipHostFree(d->h_qsets);
     if (d->d_desc_ring) hipFree(d->d_desc_ring);
     if (d->h_desc_pinned) hipHostFree(d->h_desc_pinned);
     if (d->d_slot_ids) hipFree(d->d_slot_ids);
@@ -642,6 +752,31 @@ int leon_set_quant_matrices(leon_decoder* d, const uint8_t* intra64, const uint8
     upload_tables(d);
     HIP_TRY(hipMemcpyAsync(d->d_tables, &d->h_tables, sizeof(Tables), hipMemcpyHostToDevice, d->stream));
     HIP_TRY(hipStreamSynchronize(d->stream));
+    return LEON_OK;
+}
+
+int leon_add_quant_matrices(leon_decoder* d, const uint8_t* intra64, const uint8_t* non_intra64, int32_t* set)
+{
+    if (!d || !set) return fail(LEON_ERR_INVALID, "null argument");
+    HIP_TRY(hipSetDevice(d->dev));
+    std::array<uint8_t, 128> m;
+    memcpy(m.data(), intra64 ? intra64 : kDefaultIntra, 64);
+    if (non_intra64) memcpy(m.data() + 64, non_intra64, 64); else memset(m.data() + 64, 16, 64);
+    for (size_t i = 1; i < d->qsets.size(); i++)
+        if (d->qsets[i] == m) { *set = (int32_t)i; return LEON_OK; }
+    if (!d->d_qsets) {
+        HIP_TRY(hipMalloc(&d->d_qsets, sizeof(QTables) * leon_decoder::kMaxQSets));
+        HIP_TRY(hipHostMalloc((void**)&d->h_qsets, sizeof(QTables) * leon_decoder::kMaxQSets));
+        d->qsets.assign(1, std::array<uint8_t, 128>{});
+    }
+    if ((int)d->qsets.size() >= leon_decoder::kMaxQSets)
+        return fail(LEON_ERR_INVALID, "a decoder holds at most %d different sets of quantiser matrices", leon_decoder::kMaxQSets - 1);
+    const size_t id = d->qsets.size();
+    fill_qtables(d->h_qsets[id], m.data());
+    // a set is written once and never changed: the upload is ordered in front of the launches that name it by the stream
+    HIP_TRY(hipMemcpyAsync(d->d_qsets + id, d->h_qsets + id, sizeof(QTables), hipMemcpyHostToDevice, d->stream));
+    d->qsets.push_back(m);
+    *set = (int32_t)id;
     return LEON_OK;
 }
 
@@ -1197,7 +1332,27 @@ int leon_device_malloc(int32_t device_id, size_t bytes, void** ptr, int32_t* con
 
 int leon_device_free(void* ptr)
 {
-    if (ptr) HIP_TRY(hipFree(ptr));
+    if (!ptr) return LEON_OK;
+    // like hipFree, this waits for the device: a caller may free a buffer its last launch is still writing.  A buffer
+    // of the contiguous pool is then handed to the next request instead of to the driver (big_alloc says why).
+    const int pooled_on = contig_pool().device_of(ptr);
+    int cur = 0;
+    (void)hipGetDevice(&cur);
+    if (pooled_on >= 0 && pooled_on != cur) HIP_TRY(hipSetDevice(pooled_on));
+    const hipError_t e = pooled_on >= 0 ? hipDeviceSynchronize() : hipSuccess;       // (hipFree below waits by itself)
+    if (pooled_on >= 0 && pooled_on != cur) (void)hipSetDevice(cur);
+    HIP_TRY(e);
+    HIP_TRY(big_free(ptr));
+    return LEON_OK;
+}
+
+int leon_device_pool_stats(uint64_t* held_bytes, uint64_t* in_use_bytes, int32_t* segments)
+{
+    ContigPool& P = contig_pool();
+    std::lock_guard<std::mutex> lk(P.mu);
+    if (held_bytes) *held_bytes = P.held;
+    if (in_use_bytes) *in_use_bytes = P.in_use;
+    if (segments) *segments = P.n_segments;
     return LEON_OK;
 }
 
@@ -1209,7 +1364,7 @@ int leon_measure_copy_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, do
     uint4 *src = nullptr, *dst = nullptr;
     if (big_alloc((void**)&src, bytes, kBigCaller) != hipSuccess) return fail(LEON_ERR_NOMEM, "copy source");      // allocated like the buffers it is the yardstick for
     if (big_alloc((void**)&dst, bytes, kBigCaller) != hipSuccess) {
-        hipFree(src);
+        big_free(src);
         return fail(LEON_ERR_NOMEM, "copy destination");
     }
     hipMemsetAsync(src, 0x5a, bytes, d->stream);
@@ -1227,10 +1382,56 @@ int leon_measure_copy_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, do
     hipEventElapsedTime(&ms, a, b);
     hipEventDestroy(a);
     hipEventDestroy(b);
-    hipFree(src);
-    hipFree(dst);
+    // the stream is idle; contiguous buffers return to the pool (the next call, or a decoder's ring, takes them) -- the
+    // yardstick frees nothing the copy kernel wrote in front of the pipelines bench.py runs afterwards
+    big_free(src);
+    big_free(dst);
     if (e != hipSuccess) return fail(LEON_ERR_HIP, "copy kernel: %s", hipGetErrorString(e));
     *gbps = 2.0 * (double)bytes * iters / (ms * 1e-3) / 1e9;
+    return LEON_OK;
+}
+
+int leon_measure_stream_bandwidth(leon_decoder* d, size_t bytes, int32_t iters, int32_t reads, int32_t writes, double* gbps)
+{
+    if (!d || !gbps || bytes < 4096 || iters < 1 || reads < 0 || reads > 2 || writes < 0 || writes > 2 || reads + writes == 0)
+        return fail(LEON_ERR_INVALID, "bad argument (0..2 read streams, 0..2 write streams, not both 0)");
+    HIP_TRY(hipSetDevice(d->dev));
+    bytes &= ~(size_t)4095;
+    uint4* buf[4] = {nullptr, nullptr, nullptr, nullptr};       // s0 s1 d0 d1
+    const bool want[4] = {reads >= 1, reads >= 2, true, writes >= 2};      // d0 always: the read-only kernel names it
+    auto release = [&] { for (uint4*& b : buf) { if (b) big_free(b); b = nullptr; } };
+    for (int k = 0; k < 4; k++)
+        if (want[k] && big_alloc((void**)&buf[k], bytes, kBigCaller) != hipSuccess) { release(); return fail(LEON_ERR_NOMEM, "stream buffer %d", k); }
+    for (int k = 0; k < 2; k++) if (buf[k]) hipMemsetAsync(buf[k], 0x5a, bytes, d->stream);
+    const size_t n = bytes / 16;
+    const dim3 grid((unsigned)((n + kRgbaBlock - 1) / kRgbaBlock)), block(kRgbaBlock);
+    auto launch = [&] {
+        switch (reads * 3 + writes) {
+        case 1: hipLaunchKernelGGL((k_stream16<0, 1>), grid, block, 0, d->stream, buf[0], buf[1], buf[2], buf[3], n); break;
+        case 2: hipLaunchKernelGGL((k_stream16<0, 2>), grid, block, 0, d->stream, buf[0], buf[1], buf[2], buf[3], n); break;
+        case 3: hipLaunchKernelGGL((k_stream16<1, 0>), grid, block, 0, d->stream, buf[0], buf[1], buf[2], buf[3], n); break;
+        case 4: hipLaunchKernelGGL((k_stream16<1, 1>), grid, block, 0, d->stream, buf[0], buf[1], buf[2], buf[3], n); break;
+        case 5: hipLaunchKernelGGL((k_stream16<1, 2>), grid, block, 0, d->stream, buf[0], buf[1], buf[2], buf[3], n); break;
+        case 6: hipLaunchKernelGGL((k_stream16<2, 0>), grid, block, 0, d->stream, buf[0], buf[1], buf[2], buf[3], n); break;
+        case 7: hipLaunchKernelGGL((k_stream16<2, 1>), grid, block, 0, d->stream, buf[0], buf[1], buf[2], buf[3], n); break;
+        default: hipLaunchKernelGGL((k_stream16<2, 2>), grid, block, 0, d->stream, buf[0], buf[1], buf[2], buf[3], n); break;
+        }
+    };
+    hipEvent_t a, b;
+    hipEventCreate(&a);
+    hipEventCreate(&b);
+    launch();                                   // warm-up
+    hipEventRecord(a, d->stream);
+    for (int i = 0; i < iters; i++) launch();
+    hipEventRecord(b, d->stream);
+    const hipError_t e = hipStreamSynchronize(d->stream);
+    float ms = 0;
+    hipEventElapsedTime(&ms, a, b);
+    hipEventDestroy(a);
+    hipEventDestroy(b);
+    release();                                  // the stream is idle; pooled buffers stay with the process (big_alloc)
+    if (e != hipSuccess) return fail(LEON_ERR_HIP, "stream kernel: %s", hipGetErrorString(e));
+    *gbps = (double)(reads + writes) * (double)bytes * iters / (ms * 1e-3) / 1e9;
     return LEON_OK;
 }
 

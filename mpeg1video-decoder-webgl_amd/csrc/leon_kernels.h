@@ -65,6 +65,8 @@ struct PicDesc {                 // one per picture of a batch, device resident
     uint8_t*       rgba;         // fused display conversion: frame_w x frame_h RGBA8 destination (else null)
     int32_t        no_planes;    // with rgba: the slot's planes are not written (picture is never a reference)
     int32_t        pad_;
+    const struct QTables* qt;    // the quantiser matrices of the picture's SEQUENCE (the reference reloads them at every sequence
+                                 // header, decoders/jsv.js:540-558): one of the decoder's matrix sets
 };
 
 struct Geom {
@@ -82,9 +84,13 @@ struct Geom {
     int32_t alpha;               // yuva: a fourth, luma-sized plane behind Cr; its tasks follow the chroma tasks
 };
 
-struct Tables {                  // T6, per sequence
+struct QTables {                 // T6, per sequence: 256 bytes = what a wave stages in its LDS strip (stage_tables)
     uint8_t qmT[2][8][8];        // [0 intra | 1 non-intra][column c][row i] = Q[i][c]
     uint8_t pmT[8][8];           // premultiplier, [column c][row i]
+    uint8_t pad[64];             // (in LDS these 64 bytes carry a display task's vectors: kOffCarry)
+};
+struct Tables {                  // per decoder
+    QTables q;                   // matrix set 0: leon_set_quant_matrices
     int32_t rgba_lut[1280];      // fused display conversion: fixed-point terms of YCbCrToRGBA (leon_rgba_lut.h)
 };
 
@@ -98,7 +104,7 @@ static constexpr int kRgbaBlock = 256;
 // worked on in place: coefficients -> (column pass) the int16 hand-off values w -> (row pass reads them).
 static constexpr int kLdsHalf = 1024;            // 8 rows x 128 B of int16: one block group
 static constexpr int kLdsTile = 2 * kLdsHalf;
-static constexpr int kLdsQtab = 256;             // the first 64 dwords of Tables: both matrices and the premultiplier (192 B)
+static constexpr int kLdsQtab = 256;             // a QTables: both matrices and the premultiplier (192 B) + 64 spare
 static constexpr int kLdsSlots = 128;            // column pass: the ids of the live columns, one byte each
 static constexpr int kOffQtab = kLdsTile;
 static constexpr int kOffCarry = kOffQtab + 192;  // display kernels: the 64 bytes of the table strip no table uses hold the task's 8 + 8 vectors
@@ -1018,7 +1024,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
 
 // A wave's copy of the quantiser matrices and the premultiplier (the first 64 dwords of Tables; the column pass
 // reads them by the column its lane was handed): one load and one LDS write per lane, once per wave.
-__device__ __forceinline__ void stage_tables(const Tables* __restrict__ Tg, char* lds, int lane)
+__device__ __forceinline__ void stage_tables(const QTables* __restrict__ Tg, char* lds, int lane)
 {
     const uint32_t v = reinterpret_cast<const LEON_GLOBAL uint32_t*>(gptr(Tg))[lane];
     reinterpret_cast<uint32_t*>(lds + kOffQtab)[lane] = v;
@@ -1087,8 +1093,9 @@ __global__ __launch_bounds__(kReconMaxThreads) void k_recon(const PicDesc* __res
     const int t = twg * kWavesPerWG + wave;
     if (t >= G.tasks_per_pic || pic >= G.n_pics) return;
     char* lds = smem + wave * kLdsPerWave;
-    stage_tables(T, lds, lane);
-    recon_dispatch<TYPE, SPARSE>(descs[pic], G, t, lds, lane);
+    const PicDesc& pd = descs[pic];
+    stage_tables(pd.qt, lds, lane);
+    recon_dispatch<TYPE, SPARSE>(pd, G, t, lds, lane);
 }
 
 // The same reconstruction with the display conversion fused in (see Display above).  One wave = the 8
@@ -1125,7 +1132,7 @@ void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
     const PicDesc& pd = descs[live ? pic : 0];
     const int Rt = div_inv(t, G.inv_gC), gc = t - Rt * G.gC;
     Display dsp{lds + kOffStash, 0, lds + kLdsPerWaveDisplay, reinterpret_cast<const char*>(lut_s)};
-    stage_tables(T, lds, lane);
+    stage_tables(pd.qt, lds, lane);
     MbCarry carry{};
     if (live) recon_task<TYPE, true, SPARSE, true, 0, LEON_CARRY ? 1 : 0>(pd, G, Rt, gc, lds, lane, dsp, carry);
     __syncthreads();
@@ -1318,6 +1325,23 @@ __global__ __launch_bounds__(kRgbaBlock) void k_copy16(const uint4* __restrict__
 {
     size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i < n) dst[i] = src[i];
+}
+
+// The same shape with R source streams and W destination streams (16 B per lane and stream, no loop): the yardstick for
+// launches that do not read and write in equal parts -- an I launch of the fused path writes 55-65 % of its bytes.
+// R = 0: write only; W = 0: read only (the store is there for the compiler and never happens).
+template <int R, int W>
+__global__ __launch_bounds__(kRgbaBlock) void k_stream16(const uint4* __restrict__ s0, const uint4* __restrict__ s1,
+                                                         uint4* __restrict__ d0, uint4* __restrict__ d1, size_t n)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    uint4 v = uint4{(uint32_t)i, 0x5a5a5a5au, (uint32_t)(i >> 32), 0xa5a5a5a5u};
+    if (R >= 1) v = s0[i];
+    if (R >= 2) { const uint4 u = s1[i]; v.x ^= u.x; v.y ^= u.y; v.z ^= u.z; v.w ^= u.w; }
+    if (W >= 1) d0[i] = v;
+    if (W >= 2) d1[i] = v;
+    if (W == 0 && v.x == 0x12345678u && v.y == 0x9abcdef0u && v.z == 0x0fedcba9u) d0[i] = v;      // never (sources hold 0x5a bytes)
 }
 
 }  // namespace leon

@@ -21,6 +21,7 @@ struct PipePic {                 // one parsed picture: offsets of its arrays in
     uint32_t n_entries;
     double ts_ms;
     size_t grp_off, entries, qscale, intra, repadd, mb_dir, mv_fwd, mv_bwd;   // (size_t)-1: absent
+    int32_t qm = -1;             // index into its GOP's `qms` (matrices of the sequence header in force), -1: the stream's first
 };
 
 struct Arena {                   // pinned host buffer + its device twin, one GOP at a time
@@ -39,6 +40,9 @@ struct GopJob {
     double gop_ts_ms = 0;
     int status = LEON_OK;
     std::string err;
+    // sequence headers of this shard whose quantiser matrices differ from the stream's first: the reference reloads them
+    // at every header (decoders/jsv.js:540-558), a picture is dequantised with the ones in force when it was coded
+    std::vector<std::array<uint8_t, 128>> qms;
     // gpu_parser: the slices of the GOP and its pictures as the device kernels want them (pointers into the arena's
     // device twin; VlcSlice::pic counts inside the GOP until submit_window rebases it), what of the arena is uploaded
     // (stream bytes) and what is cleared on the device (counters, error words, maps)
@@ -85,6 +89,7 @@ struct leon_pipeline {
     int W = 32, R = 2, K = 1, max_pics = 16;
     std::vector<double> st_window_done;                      // LEON_DEBUG_PIPE_TIMING: when each window completed (seconds from the start)
     uint64_t st_wait_ring_ns = 0, st_wait_scan_ns = 0;       // submit thread: waiting for a ring entry / for the window's GOPs to be parsed
+    std::string capture_dir;     // LEON_DEBUG_CAPTURE=<dir> at create: everything a window's launches read and wrote goes to files (capture_*)
     bool unfused = false;        // frame_width % 8 != 0: planes for every picture, one display conversion launch per picture
     size_t frame_bytes = 0;
 
@@ -158,7 +163,7 @@ bool arena_reserve(leon_pipeline* p, Arena* a, size_t host_need, size_t dev_need
         const size_t cap = std::max(dev_need + dev_need / 2, (size_t)8 << 20);
         char* dv = nullptr;
         if (big_alloc((void**)&dv, cap, kBigArenas) != hipSuccess) return false;
-        if (a->dev && a->dev_owned) hipFree(a->dev);        // only ever grown while the arena is being filled: nothing in flight reads it
+        if (a->dev && a->dev_owned) big_free(a->dev);        // only ever grown while the arena is being filled: nothing in flight reads it
         a->dev = dv;
         a->cap = cap;
         a->dev_owned = true;
@@ -168,24 +173,32 @@ bool arena_reserve(leon_pipeline* p, Arena* a, size_t host_need, size_t dev_need
 
 inline Arena* a_of(GopJob* job) { return job->arena; }
 
-// The pipeline takes picture size and quantiser matrices from the stream's FIRST sequence header (leon_create and
-// leon_set_quant_matrices at create time; the parsers emit raw levels, the kernels dequantise).  Every key-map entry
-// starts with a sequence header of its own and the reference reloads the matrices at each (decoders/jsv.js:540-558):
-// a shard whose header says something else would decode to wrong pixels with status OK.  Such a stream is refused.
-bool same_sequence(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, uint64_t g)
+// The pipeline takes the picture size from the stream's FIRST sequence header (leon_create).  Every key-map entry starts
+// with a sequence header of its own and the reference re-initialises at each (decoders/jsv.js:491-561): a shard whose
+// header names another SIZE cannot be decoded into this pipeline's rings and is refused; other quantiser MATRICES
+// (jsv.js:540-558) are carried with the shard's pictures and dequantised with (leon_add_quant_matrices, round 4 --
+// round 3 refused such a stream).  Returns the index of the matrices in force in job->qms, -1 = the stream's first,
+// -2 = refused (job->status / err set).
+int sequence_in_force(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, uint64_t g)
 {
     leon_vlc_info v{};
     leon_vlc_get_info(st, &v);
-    const char* what = nullptr;
     if (v.coded_width != p->vinfo.coded_width || v.coded_height != p->vinfo.coded_height ||
-        v.frame_width != p->vinfo.frame_width || v.frame_height != p->vinfo.frame_height) what = "picture size";
-    else if (memcmp(v.intra_qm, p->vinfo.intra_qm, 64) != 0) what = "intra quantiser matrix";
-    else if (memcmp(v.non_intra_qm, p->vinfo.non_intra_qm, 64) != 0) what = "non-intra quantiser matrix";
-    if (!what) return true;
-    job->status = LEON_ERR_INVALID;
-    job->err = std::string("GOP shard ") + std::to_string(g) + ": its sequence header changes the " + what +
-               " (the pipeline decodes a stream with the parameters of its first sequence header)";
-    return false;
+        v.frame_width != p->vinfo.frame_width || v.frame_height != p->vinfo.frame_height) {
+        job->status = LEON_ERR_INVALID;
+        job->err = std::string("GOP shard ") + std::to_string(g) + ": its sequence header changes the picture size (" +
+                   std::to_string(v.frame_width) + "x" + std::to_string(v.frame_height) + " after " + std::to_string(p->vinfo.frame_width) + "x" +
+                   std::to_string(p->vinfo.frame_height) + "): a pipeline decodes one size";
+        return -2;
+    }
+    if (memcmp(v.intra_qm, p->vinfo.intra_qm, 64) == 0 && memcmp(v.non_intra_qm, p->vinfo.non_intra_qm, 64) == 0) return -1;
+    std::array<uint8_t, 128> m;
+    memcpy(m.data(), v.intra_qm, 64);
+    memcpy(m.data() + 64, v.non_intra_qm, 64);
+    for (size_t i = 0; i < job->qms.size(); i++)
+        if (job->qms[i] == m) return (int)i;
+    job->qms.push_back(m);
+    return (int)job->qms.size() - 1;
 }
 
 // gpu_parser: the host reads the picture layer only (leon_vlc_scan_picture) and lays the GOP's arena out for the
@@ -193,9 +206,9 @@ bool same_sequence(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, uint64_t 
 //   [stream bytes, zero padded]                                            uploaded
 //   per picture: [macroblock records]                                      cleared on the device
 //   per picture: [maps | grp_off | entries (capacity)], per slice: [block records]      written by the kernels
-void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const uint8_t* bytes, size_t n, uint64_t g)
+void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const uint8_t* bytes, size_t n, uint64_t g, int qm_now)
 {
-    struct Scan { leon_vlc_picture_scan s; std::vector<int32_t> code; std::vector<uint64_t> pos; };
+    struct Scan { leon_vlc_picture_scan s; std::vector<int32_t> code; std::vector<uint64_t> pos; int qm; };
     std::vector<Scan> scans;
     for (;;) {
         leon_vlc_picture_scan sc;
@@ -206,10 +219,11 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
             job->err = std::string("GOP shard ") + std::to_string(g) + ": " + leon_vlc_last_error();
             return;
         }
-        if (sc.new_sequence && !same_sequence(p, job, st, g)) return;
+        if (sc.new_sequence && (qm_now = sequence_in_force(p, job, st, g)) == -2) return;
         if (sc.open_gop) job->open_gop = true;
         Scan x;
         x.s = sc;
+        x.qm = qm_now;
         x.code.assign(sc.slice_code, sc.slice_code + sc.n_slices);
         x.pos.assign(sc.slice_bit_pos, sc.slice_bit_pos + sc.n_slices);
         scans.push_back(std::move(x));
@@ -260,6 +274,7 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
         m.type = x.s.type;
         m.tref = x.s.temporal_reference;
         m.ts_ms = x.s.ts_ms;
+        m.qm = x.qm;
         leon::VlcPic v{};
         v.type = x.s.type;
         v.full_pel_fwd = x.s.full_pel_fwd; v.fwd_rsize = x.s.fwd_rsize;
@@ -323,7 +338,8 @@ void parse_gop(leon_pipeline* p, GopJob* job)
         job->err = std::string("GOP shard ") + std::to_string(g) + ": " + leon_vlc_last_error();
         return;
     }
-    if (!same_sequence(p, job, st, g)) {
+    int qm_now = sequence_in_force(p, job, st, g);        // the shard's own sequence header (read by leon_vlc_open*)
+    if (qm_now == -2) {
         leon_vlc_close(st);
         return;
     }
@@ -332,7 +348,7 @@ void parse_gop(leon_pipeline* p, GopJob* job)
     Arena* a = job->arena;
     a->used = 0;
     if (p->gpu_parser) {
-        scan_gop_for_gpu(p, job, st, b, n, g);
+        scan_gop_for_gpu(p, job, st, b, n, g, qm_now);
         leon_vlc_close(st);
         return;
     }
@@ -345,7 +361,7 @@ void parse_gop(leon_pipeline* p, GopJob* job)
             job->err = std::string("GOP shard ") + std::to_string(g) + ": " + leon_vlc_last_error();
             break;
         }
-        if (pic.new_sequence && !same_sequence(p, job, st, g)) break;
+        if (pic.new_sequence && (qm_now = sequence_in_force(p, job, st, g)) == -2) break;
         if (pic.open_gop) job->open_gop = true;
         const size_t epad = pad256((size_t)pic.n_entries * 4 + 4);
         const size_t need = a->used + gpad + epad + 4 * mpad + 2 * vpad;
@@ -359,6 +375,7 @@ void parse_gop(leon_pipeline* p, GopJob* job)
         m.tref = pic.temporal_reference;
         m.n_entries = pic.n_entries;
         m.ts_ms = pic.ts_ms;
+        m.qm = qm_now;
         auto put = [&](const void* src, size_t nbytes, size_t reserve) -> size_t {
             if (!src) return kNone;
             const size_t at = a->used;
@@ -524,6 +541,20 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
     return LEON_OK;
 }
 
+// LEON_DEBUG_CAPTURE=<dir> (read when the pipeline is created; tests/test_pipeline_gpu.py sets it for its small streams):
+// what the reconstruction launches of a window READ and WROTE is written to <dir>/w<window>/ -- after every level, with
+// the decoder's stream idle, the planes of the slot each picture of the level wrote and of the slots it predicted from
+// (L<level>_g<lane>_t<tref>_{out,fwd,bwd}.planes); after the last level every GOP's device arena as the kernels left it
+// (arena_<lane>.bin: stream bytes, the GPU parser's records, maps, group offsets, entry lists) with an index of where each
+// picture's arrays lie (index.txt).  A wrong frame then comes with the inputs that produced it: which buffer held wrong
+// bytes separates a late write into reused pages from a read of memory nobody wrote.  Serialises the levels.
+void capture_file(const std::string& path, const void* dev, size_t bytes)
+{
+    std::vector<char> h(bytes);
+    if (bytes && hipMemcpy(h.data(), dev, bytes, hipMemcpyDeviceToHost) != hipSuccess) return;
+    if (FILE* f = fopen(path.c_str(), "wb")) { fwrite(h.data(), 1, bytes, f); fclose(f); }
+}
+
 // the pictures of one window as launches: per GOP the anchors rotate through three slots; a picture's
 // level is one more than the deepest picture it predicts from, and a level is one batch
 int submit_window(leon_pipeline* p, PipeWindow* w)
@@ -611,6 +642,26 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
         HIP_TRY(hipStreamWaitEvent(d->stream, copied, 0));
         d->ev_pool.push_back(copied);
     }
+    // the matrix sets of shards whose sequence headers carry other matrices than the stream's first: registered with the
+    // decoder here, on the one thread that drives it (the upload is ordered in front of the launches by the stream)
+    std::vector<std::vector<int32_t>> qset(lanes);
+    for (size_t j = 0; j < lanes; j++)
+        for (const auto& m : w->jobs[j]->qms) {
+            int32_t id = 0;
+            const int rc = leon_add_quant_matrices(d, m.data(), m.data() + 64, &id);
+            if (rc != LEON_OK) return rc;
+            qset[j].push_back(id);
+        }
+    const bool capture = !p->capture_dir.empty();
+    const std::string cdir = capture ? p->capture_dir + "/w" + std::to_string(w->id) : std::string();
+    FILE* cidx = nullptr;
+    if (capture) {
+        (void)!system(("mkdir -p '" + cdir + "'").c_str());
+        cidx = fopen((cdir + "/index.txt").c_str(), "w");
+        if (cidx) fprintf(cidx, "geom coded=%dx%d frame=%dx%d mbs=%d n_groups=%d gpu_parser=%d unfused=%d slot_bytes=%zu\n", p->vinfo.coded_width, p->vinfo.coded_height,
+                          p->vinfo.frame_width, p->vinfo.frame_height, p->vinfo.mb_width * p->vinfo.mb_height, p->vinfo.n_groups, (int)p->gpu_parser, (int)p->unfused, d->plane_bytes);
+    }
+    size_t lvl_no = 0;
     std::vector<leon_sparse_picture> batch;
     for (auto& lvl : levels) {
         batch.clear();
@@ -634,6 +685,7 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
             sp.mv_bwd = (const int16_t*)ptr(m.mv_bwd);
             sp.rgba_out = p->unfused ? nullptr : ring + ((size_t)it.lane * p->max_pics + (size_t)m.tref) * p->frame_bytes;
             sp.no_planes = !p->unfused && m.type == LEON_PIC_B;
+            sp.qm_set = m.qm >= 0 ? qset[it.lane][(size_t)m.qm] : 0;
             batch.push_back(sp);
         }
         if (batch.empty()) continue;
@@ -644,6 +696,24 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
                 rc = leon_convert_rgba(d, it.out, ring + ((size_t)it.lane * p->max_pics + (size_t)it.pic->tref) * p->frame_bytes, LEON_MEM_DEVICE, LEON_RGB_CPU_TWIN);
                 if (rc != LEON_OK) return rc;
             }
+        if (capture) {
+            HIP_TRY(hipStreamSynchronize(d->stream));
+            for (const Item& it : lvl) {
+                const PipePic& m = *it.pic;
+                const std::string stem = cdir + "/L" + std::to_string(lvl_no) + "_g" + std::to_string(it.lane) + "_t" + std::to_string(m.tref);
+                if (it.out >= 0) capture_file(stem + "_out.planes", d->d_slots + (size_t)it.out * d->slot_stride, d->plane_bytes);
+                if (it.fwd >= 0) capture_file(stem + "_fwd.planes", d->d_slots + (size_t)it.fwd * d->slot_stride, d->plane_bytes);
+                if (it.bwd >= 0) capture_file(stem + "_bwd.planes", d->d_slots + (size_t)it.bwd * d->slot_stride, d->plane_bytes);
+                if (cidx) fprintf(cidx, "pic lane=%zu gop=%llu tref=%d type=%d level=%zu out=%d fwd=%d bwd=%d n_entries=%u qm=%d grp_off=%zd entries=%zd qscale=%zd intra=%zd repadd=%zd "
+                                        "mb_dir=%zd mv_fwd=%zd mv_bwd=%zd\n", it.lane, (unsigned long long)w->jobs[it.lane]->key_gop, m.tref, m.type, lvl_no, it.out, it.fwd, it.bwd,
+                                  m.n_entries, m.qm, (ssize_t)m.grp_off, (ssize_t)m.entries, (ssize_t)m.qscale, (ssize_t)m.intra, (ssize_t)m.repadd, (ssize_t)m.mb_dir, (ssize_t)m.mv_fwd, (ssize_t)m.mv_bwd);
+            }
+        }
+        lvl_no++;
+    }
+    if (capture) {
+        for (size_t j = 0; j < lanes; j++) capture_file(cdir + "/arena_" + std::to_string(j) + ".bin", w->jobs[j]->arena->dev, w->jobs[j]->arena->used);
+        if (cidx) fclose(cidx);
     }
     if (serial) HIP_TRY(hipStreamSynchronize(d->stream));
     HIP_TRY(hipEventRecord(w->done, d->stream));
@@ -872,6 +942,7 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
     p->valid = valid_bytes;
     p->cb = cb;
     p->user = user;
+    if (const char* cd = getenv("LEON_DEBUG_CAPTURE")) p->capture_dir = cd;
     if (n_keys > 0) {
         for (int g = 0; g < n_keys; g++) {
             const uint64_t b = offs[(size_t)g], e = g + 1 < n_keys ? offs[(size_t)g + 1] : bytes;
@@ -901,6 +972,15 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
     p->W = cfg->gops_per_window > 0 ? cfg->gops_per_window : 32;
     if ((uint64_t)p->W > p->total_gops) p->W = (int)p->total_gops;
     p->gpu_parser = cfg->gpu_parser >= 0;          // 0 = default: the GPU (a pipeline has a device by construction); < 0: the parser threads
+    if (cfg->gpu_parser == LEON_PIPELINE_PARSER_DEFAULT) {
+        // a caller who did not ASK for the GPU parser is not refused for its limits: a picture whose group counters do not fit
+        // k_vlc_index's LDS, or a GOP shard of 2^28 bytes and more (the kernels count bits in 32), goes to the parser threads
+        bool fits = ((size_t)p->vinfo.n_groups + leon::kVlcIndexThreads) * 4 <= (size_t)160 * 1024 - 512;
+        for (uint32_t g : p->mine) fits = fits && p->shard_end[g] - p->shard_begin[g] < ((uint64_t)1 << 28);
+        if (getenv("LEON_DEBUG_GPU_PARSER_LIMIT") && p->vinfo.n_groups > atoi(getenv("LEON_DEBUG_GPU_PARSER_LIMIT"))) fits = false;      // tests: a mocked n_groups limit
+        if (!fits) p->gpu_parser = false;
+    }
+    p->info.gpu_parser = p->gpu_parser ? 1 : 0;
     p->R = cfg->windows_in_flight > 0 ? cfg->windows_in_flight : (p->gpu_parser ? 3 : 2);      // GPU parser: one window being parsed beside one reconstructed and one read
     if (cfg->max_gop_pictures > 0) p->max_pics = cfg->max_gop_pictures;
     else if (valid_bytes < bytes) p->max_pics = 16;          // still arriving: nothing to count yet
@@ -1048,7 +1128,7 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
         }
         // k_vlc_index counts a picture's groups in LDS (one workgroup may have all 160 KiB of a CU)
         p->vlc_index_lds = ((size_t)p->vinfo.n_groups + leon::kVlcIndexThreads) * 4;
-        if (p->vlc_index_lds > 160 * 1024 - 512) return bail(LEON_ERR_INVALID, "picture too large for the GPU parser (its group counters do not fit in LDS): use LEON_PIPELINE_PARSER_HOST");
+        if (p->vlc_index_lds > 160 * 1024 - 512) return bail(LEON_ERR_INVALID, "picture too large for the GPU parser (its group counters do not fit in LDS): use LEON_PIPELINE_PARSER_HOST or LEON_PIPELINE_PARSER_DEFAULT");
         if (p->vlc_index_lds > 48 * 1024 &&
             hipFuncSetAttribute((const void*)leon::k_vlc_index, hipFuncAttributeMaxDynamicSharedMemorySize, (int)p->vlc_index_lds) != hipSuccess)
             return bail(LEON_ERR_HIP, "LDS of the GPU parser's index kernel");
@@ -1084,7 +1164,7 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
                     a->host = p->slab_host + (size_t)i * host_each; a->host_cap = host_each; a->host_owned = false;
                 }
             } else {
-                if (p->slab_dev) hipFree(p->slab_dev);
+                if (p->slab_dev) big_free(p->slab_dev);
                 p->slab_dev = nullptr;
                 (void)hipGetLastError();
             }
@@ -1186,11 +1266,11 @@ void leon_pipeline_destroy(leon_pipeline* p)
     }
     for (Arena* a : p->all_arenas) {
         if (a->host && a->host_owned) hipHostFree(a->host);
-        if (a->dev && a->dev_owned) hipFree(a->dev);
+        if (a->dev && a->dev_owned) big_free(a->dev);
         delete a;
     }
     if (p->slab_host) hipHostFree(p->slab_host);
-    if (p->slab_dev) hipFree(p->slab_dev);
+    if (p->slab_dev) big_free(p->slab_dev);
     if (getenv("LEON_DEBUG_PIPE_TIMING"))      // where the submit thread's time went (LEON_DEBUG_PIPE_TIMING=1)
         fprintf(stderr, "leon pipeline: %llu windows; per window on the submit thread: %.2f ms waiting for a ring entry, %.2f ms waiting for the window's GOPs "
                         "(parser threads), %.2f ms in submit_window\n", (unsigned long long)p->windows_submitted,
@@ -1210,7 +1290,7 @@ void leon_pipeline_destroy(leon_pipeline* p)
     if (p->d_vlc_tables) hipFree(p->d_vlc_tables);
     for (hipStream_t vs : p->vlc_stream)
         if (vs) hipStreamDestroy(vs);
-    if (p->d_rgba) hipFree(p->d_rgba);
+    if (p->d_rgba) big_free(p->d_rgba);
     if (p->copy_stream) hipStreamDestroy(p->copy_stream);
     if (p->dec) leon_destroy(p->dec);
     delete p;

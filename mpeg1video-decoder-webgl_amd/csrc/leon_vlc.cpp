@@ -914,6 +914,8 @@ void ahead_wait(leon_vlc_stream* s);
 
 extern "C" {
 
+int leon_vlc_abi_version(void) { return LEON_VLC_ABI_VERSION; }
+
 const char* leon_vlc_last_error(void) { return g_err; }
 
 int leon_vlc_open(const uint8_t* data, size_t n, int32_t threads, leon_vlc_stream** out)

@@ -20,15 +20,16 @@ RGB_CPU_TWIN, RGB_GL = 0, 1
 
 # every symbol include/leon.h declares (tests check the library exports all of them)
 SYMBOLS = [
-    "leon_abi_version", "leon_last_error", "leon_create", "leon_destroy", "leon_set_quant_matrices",
+    "leon_abi_version", "leon_last_error", "leon_create", "leon_destroy", "leon_set_quant_matrices", "leon_add_quant_matrices",
     "leon_acquire_slot", "leon_release_slot", "leon_free_decoded_slots", "leon_submit_picture",
     "leon_submit_batch", "leon_batch_create", "leon_batch_run", "leon_batch_destroy",
     "leon_submit_sparse", "leon_batch_create_sparse",
     "leon_convert_rgba", "leon_convert_rgba_batch", "leon_read_planes", "leon_write_planes",
     "leon_read_alpha_plane", "leon_write_alpha_plane", "leon_slot_device_ptr", "leon_sync", "leon_set_overlap_convert", "leon_timing_enable", "leon_timing_reset", "leon_timing_get",
     "leon_timing_get_launches",
-    "leon_measure_copy_bandwidth", "leon_device_malloc", "leon_device_free",
+    "leon_measure_copy_bandwidth", "leon_measure_stream_bandwidth", "leon_device_malloc", "leon_device_free", "leon_device_pool_stats",
 ]
+ABI_VERSION = 3        # LEON_ABI_VERSION of include/leon.h
 # include/leon_pipeline.h (same library)
 PIPELINE_SYMBOLS = [
     "leon_pipeline_create", "leon_pipeline_create_partial", "leon_pipeline_feed", "leon_pipeline_get_info", "leon_pipeline_release_window", "leon_pipeline_wait",
@@ -55,7 +56,7 @@ class Picture(C.Structure):
                 ("repadd", C.c_void_p), ("mv_fwd", C.c_void_p), ("mv_bwd", C.c_void_p),
                 ("mb_dir", C.c_void_p),
                 # ABI 2: fused display conversion (device pointer to the RGBA frame, or NULL)
-                ("rgba_out", C.c_void_p), ("no_planes", C.c_int32), ("reserved", C.c_int32),
+                ("rgba_out", C.c_void_p), ("no_planes", C.c_int32), ("qm_set", C.c_int32),      # qm_set: ABI 3
                 ("coef_a", C.c_void_p)]
 
 
@@ -64,7 +65,7 @@ class SparsePicture(C.Structure):
                 ("ref_bwd_slot", C.c_int32), ("grp_off", C.c_void_p), ("entries", C.c_void_p),
                 ("n_entries", C.c_uint32), ("reserved", C.c_int32), ("qscale", C.c_void_p), ("intra", C.c_void_p),
                 ("repadd", C.c_void_p), ("mv_fwd", C.c_void_p), ("mv_bwd", C.c_void_p), ("mb_dir", C.c_void_p),
-                ("rgba_out", C.c_void_p), ("no_planes", C.c_int32), ("reserved2", C.c_int32)]
+                ("rgba_out", C.c_void_p), ("no_planes", C.c_int32), ("qm_set", C.c_int32)]
 
 
 class KernelStats(C.Structure):
@@ -97,7 +98,8 @@ class PipelineFrame(C.Structure):
 class PipelineInfo(C.Structure):
     _fields_ = [("coded_width", C.c_int32), ("coded_height", C.c_int32), ("frame_width", C.c_int32), ("frame_height", C.c_int32),
                 ("picture_rate", C.c_double), ("duration", C.c_double), ("gops", C.c_uint32), ("shard_gops", C.c_uint32),
-                ("first_gop", C.c_uint32), ("parser_threads", C.c_int32), ("gops_per_window", C.c_int32)]
+                ("first_gop", C.c_uint32), ("parser_threads", C.c_int32), ("gops_per_window", C.c_int32),
+                ("gpu_parser", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PipelineStats(C.Structure):
@@ -128,11 +130,14 @@ def load():
         raise ImportError("libleon_hip.so is not built: run `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C mpeg1video-decoder-webgl_amd/csrc` (no CPU fallback exists)")
     lib = C.CDLL(path)
+    if lib.leon_abi_version() != ABI_VERSION:
+        raise ImportError("libleon_hip.so (%s) speaks ABI %d, this binding ABI %d: rebuild it" % (path, lib.leon_abi_version(), ABI_VERSION))
     lib.leon_last_error.restype = C.c_char_p
     lib.leon_create.argtypes = [C.POINTER(Config), C.POINTER(C.c_void_p)]
     lib.leon_destroy.argtypes = [C.c_void_p]
     lib.leon_destroy.restype = None
     lib.leon_set_quant_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.leon_add_quant_matrices.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_int32)]
     lib.leon_acquire_slot.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
     lib.leon_release_slot.argtypes = [C.c_void_p, C.c_int32]
     lib.leon_free_decoded_slots.argtypes = [C.c_void_p]
@@ -158,6 +163,8 @@ def load():
     lib.leon_timing_get.argtypes = [C.c_void_p, C.c_int32, C.POINTER(KernelStats)]
     lib.leon_timing_get_launches.argtypes = [C.c_void_p, C.POINTER(LaunchTime), C.c_int32, C.POINTER(C.c_int32)]
     lib.leon_measure_copy_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_double)]
+    lib.leon_measure_stream_bandwidth.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_double)]
+    lib.leon_device_pool_stats.argtypes = [C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_int32)]
     lib.leon_device_malloc.argtypes = [C.c_int32, C.c_size_t, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)]
     lib.leon_device_free.argtypes = [C.c_void_p]
     lib.leon_pipeline_create.argtypes = [C.POINTER(PipelineConfig), C.c_void_p, C.c_size_t, PIPELINE_CB, C.c_void_p, C.POINTER(C.c_void_p)]
@@ -191,7 +198,7 @@ def _hostptr(a, dtype, keep):
 
 def make_picture(ptype, out_slot, coef_y, coef_cb, coef_cr, qscale, intra, repadd=None, mv_fwd=None,
                  mv_bwd=None, mb_dir=None, ref_fwd_slot=-1, ref_bwd_slot=-1, keep=None, device=False,
-                 rgba_out=None, no_planes=False, coef_a=None):
+                 rgba_out=None, no_planes=False, coef_a=None, qm_set=0):
     """Fill a Picture from numpy arrays (host) or raw device addresses (device=True: ints).
     rgba_out: device address of the RGBA frame for the fused display conversion (always a device address);
     coef_a: the A plane's levels for a yuva decoder."""
@@ -199,6 +206,7 @@ def make_picture(ptype, out_slot, coef_y, coef_cb, coef_cr, qscale, intra, repad
     p.type, p.out_slot, p.ref_fwd_slot, p.ref_bwd_slot = ptype, out_slot, ref_fwd_slot, ref_bwd_slot
     p.rgba_out = None if rgba_out is None else int(rgba_out)
     p.no_planes = 1 if no_planes else 0
+    p.qm_set = int(qm_set)
     if device:
         vals = (coef_y, coef_cb, coef_cr, qscale, intra, repadd, mv_fwd, mv_bwd, mb_dir)
         (p.coef_y, p.coef_cb, p.coef_cr, p.qscale, p.intra, p.repadd, p.mv_fwd, p.mv_bwd, p.mb_dir) = \
@@ -222,9 +230,10 @@ def make_picture(ptype, out_slot, coef_y, coef_cb, coef_cr, qscale, intra, repad
 
 def make_sparse_picture(ptype, out_slot, grp_off, entries, n_entries, qscale, intra, repadd=None, mv_fwd=None,
                         mv_bwd=None, mb_dir=None, ref_fwd_slot=-1, ref_bwd_slot=-1, keep=None, device=False,
-                        rgba_out=None, no_planes=False):
+                        rgba_out=None, no_planes=False, qm_set=0):
     """The sparse-boundary twin of make_picture (lists in the format of include/leon_vlc.h)."""
     p = SparsePicture()
+    p.qm_set = int(qm_set)
     p.type, p.out_slot, p.ref_fwd_slot, p.ref_bwd_slot = ptype, out_slot, ref_fwd_slot, ref_bwd_slot
     p.rgba_out = None if rgba_out is None else int(rgba_out)
     p.no_planes = 1 if no_planes else 0
@@ -275,6 +284,12 @@ class Decoder:
     def set_quant_matrices(self, intra=None, non_intra=None):
         keep = []
         _chk(self.lib.leon_set_quant_matrices(self.h, _hostptr(intra, np.uint8, keep), _hostptr(non_intra, np.uint8, keep)))
+
+    def add_quant_matrices(self, intra=None, non_intra=None):
+        """a further set of matrices beside set 0; returns the id pictures name in qm_set"""
+        keep, s = [], C.c_int32()
+        _chk(self.lib.leon_add_quant_matrices(self.h, _hostptr(intra, np.uint8, keep), _hostptr(non_intra, np.uint8, keep), C.byref(s)))
+        return s.value
 
     def acquire_slot(self):
         s = C.c_int32()
@@ -384,6 +399,37 @@ class Decoder:
         _chk(self.lib.leon_measure_copy_bandwidth(self.h, nbytes, iters, C.byref(g)))
         return g.value
 
+    def measure_stream_bandwidth(self, nbytes=1 << 31, iters=10, reads=1, writes=1):
+        """GB/s over all streams of the 16-byte-per-lane kernel with `reads` source and `writes` destination streams"""
+        g = C.c_double()
+        _chk(self.lib.leon_measure_stream_bandwidth(self.h, nbytes, iters, reads, writes, C.byref(g)))
+        return g.value
+
+
+class _Frames:
+    """the frames of a delivered window as a read-only sequence of dicts, made when asked for (a 128-GOP window has 1536 of
+    them; a callback that looks at a dozen should not pay for the rest on the pipeline's notify thread)"""
+
+    def __init__(self, frames, n, pipe):
+        self._f, self._n, self._pipe = frames, n, pipe
+
+    def __len__(self):
+        return self._n
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(self._n))]
+        if i < 0:
+            i += self._n
+        if not 0 <= i < self._n:
+            raise IndexError(i)
+        f = self._f[i]
+        return {"gop": int(f.gop), "display_index": f.display_index, "type": f.type, "ts_ms": f.ts_ms, "rgba": f.rgba,
+                "_i": i, "_frames": self._f, "_pipe": self._pipe}
+
+    def __iter__(self):
+        return (self[i] for i in range(self._n))
+
 
 class Pipeline:
     """leon_pipeline_* (include/leon_pipeline.h): stream bytes in, RGBA frames in device memory out.
@@ -425,8 +471,7 @@ class Pipeline:
                 if self._on_window is not None:
                     # `_pipe`: a callback may read frames through the dicts alone (read_frame(f) below), without the
                     # variable its caller assigns the pipeline to -- which does not exist yet while the constructor runs
-                    fl = [{"gop": int(frames[i].gop), "display_index": frames[i].display_index, "type": frames[i].type,
-                           "ts_ms": frames[i].ts_ms, "rgba": frames[i].rgba, "_i": i, "_frames": frames, "_pipe": self} for i in range(n)]
+                    fl = _Frames(frames, n, self)
                     keep = self._on_window(window, fl)
                 if keep is not False:
                     _release(window)
@@ -459,7 +504,12 @@ class Pipeline:
     def feed(self, valid_bytes, chunk=None, offset=None):
         """more of the stream has arrived: optionally copy `chunk` to `offset` of the pipeline's buffer first"""
         if chunk is not None:
-            C.memmove(C.addressof(self._data) + int(offset), bytes(chunk), len(chunk))
+            if offset is None:
+                raise ValueError("feed(chunk=...) needs the offset the chunk belongs at")
+            offset, chunk = int(offset), bytes(chunk)
+            if offset < 0 or offset + len(chunk) > len(self._data):
+                raise ValueError("chunk of %d bytes at offset %d does not fit the stream buffer of %d bytes" % (len(chunk), offset, len(self._data)))
+            C.memmove(C.addressof(self._data) + offset, chunk, len(chunk))
         _chk(self.lib.leon_pipeline_feed(self.h, int(valid_bytes)))
 
     def release_window(self, window):
@@ -486,6 +536,25 @@ class Pipeline:
             self.close()
         except Exception:
             pass
+
+
+def pool_stats():
+    """leon_device_pool_stats: contiguous memory this process holds (never returned to the driver), how much is handed out"""
+    held, used, seg = C.c_uint64(), C.c_uint64(), C.c_int32()
+    _chk(load().leon_device_pool_stats(C.byref(held), C.byref(used), C.byref(seg)))
+    return {"held_bytes": held.value, "in_use_bytes": used.value, "segments": seg.value}
+
+
+def device_view(ptr, nbytes, device_id=0):
+    """`nbytes` of device memory at `ptr` as a torch uint8 tensor, without copying (the memory must outlive the tensor):
+    how bench.py and the tests checksum the pipeline's frames where they lie"""
+    import torch
+
+    class _View:
+        pass
+    v = _View()
+    v.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+    return torch.as_tensor(v, device="cuda:%d" % device_id)
 
 
 class DeviceBuffer:

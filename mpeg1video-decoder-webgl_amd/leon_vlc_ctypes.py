@@ -7,7 +7,8 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-SYMBOLS = ["leon_vlc_last_error", "leon_vlc_open", "leon_vlc_open_shard", "leon_vlc_open_scan", "leon_vlc_close", "leon_vlc_get_info",
+ABI_VERSION = 2        # LEON_VLC_ABI_VERSION of include/leon_vlc.h
+SYMBOLS = ["leon_vlc_abi_version", "leon_vlc_last_error", "leon_vlc_open", "leon_vlc_open_shard", "leon_vlc_open_scan", "leon_vlc_close", "leon_vlc_get_info",
            "leon_vlc_next_picture", "leon_vlc_next_picture_sync", "leon_vlc_seek", "leon_vlc_densify", "leon_vlc_densify_alpha", "leon_vlc_get_keymap",
            "leon_vlc_scan_picture", "leon_vlc_get_gpu_tables"]
 
@@ -53,6 +54,8 @@ def load():
     if not os.path.exists(path):
         raise RuntimeError("libleon_vlc.so is missing (%s): run `make -C mpeg1video-decoder-webgl_amd/csrc`" % path)
     lib = C.CDLL(path)
+    if not hasattr(lib, "leon_vlc_abi_version") or lib.leon_vlc_abi_version() != ABI_VERSION:
+        raise RuntimeError("libleon_vlc.so (%s) does not speak ABI %d of include/leon_vlc.h: rebuild it" % (path, ABI_VERSION))
     lib.leon_vlc_last_error.restype = C.c_char_p
     lib.leon_vlc_open.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.POINTER(C.c_void_p)]
     lib.leon_vlc_open_shard.argtypes = [C.c_void_p, C.c_size_t, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]

@@ -599,10 +599,28 @@ napi_value CreatePipeline(napi_env env, napi_callback_info info)
     napi_create_reference(env, argv[0], 1, &h->stream_ref);
     // validBytes: the stream is still arriving (leon_pipeline_create_partial) -- the loader writes on into the same
     // Buffer and calls feed(validBytesNow), as addBuffer does in the reference (features/bitreader.js:332-430)
-    int32_t valid = -1;
-    get_i32(env, argv[1], "validBytes", &valid, -1);
-    int rc = valid >= 0 ? leon_pipeline_create_partial(&cfg, (const uint8_t*)data, len, (size_t)valid, pipe_native_cb, h, &h->p)
-                        : leon_pipeline_create(&cfg, (const uint8_t*)data, len, pipe_native_cb, h, &h->p);
+    // (a presence test and a double, not an int32 with -1 for "absent": 2 GiB and more of a stream may have arrived)
+    bool partial = false;
+    double valid = 0;
+    {
+        napi_value v;
+        bool has = false;
+        if (napi_has_named_property(env, argv[1], "validBytes", &has) == napi_ok && has && napi_get_named_property(env, argv[1], "validBytes", &v) == napi_ok) {
+            napi_valuetype t;
+            if (napi_typeof(env, v, &t) == napi_ok && t != napi_undefined && t != napi_null) {
+                if (t != napi_number || napi_get_value_double(env, v, &valid) != napi_ok || !(valid >= 0) || valid > (double)len || valid != (double)(size_t)valid) {
+                    napi_release_threadsafe_function(h->tsfn, napi_tsfn_abort);
+                    napi_delete_reference(env, h->stream_ref);
+                    delete h;
+                    napi_throw_range_error(env, nullptr, "createPipeline: validBytes must be an integer between 0 and the stream's length");
+                    return nullptr;
+                }
+                partial = true;
+            }
+        }
+    }
+    int rc = partial ? leon_pipeline_create_partial(&cfg, (const uint8_t*)data, len, (size_t)valid, pipe_native_cb, h, &h->p)
+                     : leon_pipeline_create(&cfg, (const uint8_t*)data, len, pipe_native_cb, h, &h->p);
     if (rc != LEON_OK) {
         napi_release_threadsafe_function(h->tsfn, napi_tsfn_abort);
         napi_delete_reference(env, h->stream_ref);
@@ -632,6 +650,10 @@ napi_value AbiVersion(napi_env env, napi_callback_info)
 
 napi_value Init(napi_env env, napi_value exports)
 {
+    if (leon_abi_version() != LEON_ABI_VERSION) {      // the addon was compiled against another include/leon.h than the library it found
+        napi_throw_error(env, nullptr, "leon_napi: libleon_hip.so speaks another ABI version than this addon was built for; rebuild both");
+        return exports;
+    }
     napi_value fn;
     NAPI_OK(napi_create_function(env, "create", NAPI_AUTO_LENGTH, Create, nullptr, &fn));
     NAPI_OK(napi_set_named_property(env, exports, "create", fn));

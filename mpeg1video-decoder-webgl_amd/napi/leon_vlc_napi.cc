@@ -184,6 +184,10 @@ napi_value Open(napi_env env, napi_callback_info info)
 
 napi_value Init(napi_env env, napi_value exports)
 {
+    if (leon_vlc_abi_version() != LEON_VLC_ABI_VERSION) {      // built against another include/leon_vlc.h than the library it found
+        napi_throw_error(env, nullptr, "leon_vlc_napi: libleon_vlc.so speaks another ABI version than this addon was built for; rebuild both");
+        return exports;
+    }
     napi_value fn;
     napi_create_function(env, "open", NAPI_AUTO_LENGTH, Open, nullptr, &fn);
     napi_set_named_property(env, exports, "open", fn);

@@ -102,3 +102,31 @@ def test_stream_through_native_front_end_and_hip(L, s, fused):
         assert n == len(s["pictures"])
     finally:
         dec.close()
+
+
+def test_gl_flavour_kernel_against_the_executed_references_canvas(L):
+    """the display path the reference actually runs -- renderFrameGL + SHADER_FRAGMENT_YCBCRTORGBA, fp32
+    (player/easybits.player.js:2787-2858, player/parts/end.js:77-156) -- executed on softgl: the `canvas` of
+    tests/golden/glsl_streams.json.  leon_convert_rgba(LEON_RGB_GL) (k_rgba_gl) on the same fixture planes stays within
+    1 LSB of it (decision D10: the order of the four products of `vec4 * mat4` is the GLSL compiler's), alpha 255, on the
+    crop geometry (frame size < coded size included); and equals the oracle's GL flavour bit for bit."""
+    from oracle import oracle_py as O
+    worst, n = 0, 0
+    for s in STREAMS:
+        cw, ch, fw, fh = s["coded_w"], s["coded_h"], s["frame_w"], s["frame_h"]
+        dec = L.Decoder(cw, ch, fw, fh, n_slots=2)
+        try:
+            for r in s["pictures"]:
+                if "canvas" not in r:
+                    continue
+                y, cb, cr = (unz(x) for x in r["planes"])
+                dec.write_planes(1, y.reshape(ch, cw), cb.reshape(ch // 2, cw // 2), cr.reshape(ch // 2, cw // 2))
+                got = dec.convert_rgba(1, L.RGB_GL)
+                canvas = unz(r["canvas"]).reshape(fh, fw, 4)[::-1]              # GL rows are bottom-up
+                assert got.shape == canvas.shape and (got[..., 3] == 255).all()
+                worst = max(worst, int(np.abs(got.astype(int) - canvas.astype(int)).max()))
+                assert np.array_equal(got, O.ycbcr_to_rgba(y, cb, cr, cw, fw, fh, "gl")), "k_rgba_gl differs from the oracle's GL flavour"
+                n += 1
+        finally:
+            dec.close()
+    assert n > 0 and worst <= 1, (n, worst)

@@ -67,7 +67,8 @@ def test_same_frames_as_the_host_front_end_at_1080p(L):
 def test_sixteen_different_1080p_gops_same_frames_from_both_front_ends(L):
     """the stream the end-to-end figures are quoted on (tools/stream_1080p.py ensure_varied: 16 closed IBBP GOPs of different
     content, quantiser scales 2 .. 31 by row, 192 pictures): every frame of the GPU-parsed pipeline equals the host-parsed
-    one (SHA-256 per frame; the two-GOP stream above is the one checked against the oracle)"""
+    one (SHA-256 per frame), and two of its GOPs equal the ORACLE's frames too (two product paths agreeing with
+    each other is not parity; the two-GOP stream above is checked against the oracle in full)"""
     import hashlib
     import stream_1080p
     data = stream_1080p.load_varied()
@@ -89,6 +90,11 @@ def test_sixteen_different_1080p_gops_same_frames_from_both_front_ends(L):
     assert len(gpu) == 16 * 12 and sorted(gpu) == sorted(host)
     bad = [k for k in sorted(gpu) if gpu[k] != host[k]]
     assert not bad, bad[:8]
+    import bench
+    want = bench.oracle_stream_sums(data, [3, 11], threads=2, digest=lambda rgba: hashlib.sha256(np.ascontiguousarray(rgba).tobytes()).hexdigest())
+    assert len(want) == 24
+    bad = [k for k in sorted(want) if gpu[k] != want[k]]
+    assert not bad, "frames that differ from the oracle: %s" % bad[:8]
 
 
 def test_damaged_streams_are_refused(L):

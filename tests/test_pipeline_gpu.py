@@ -21,14 +21,18 @@ def L():
     return leon_ctypes
 
 
-def oracle_frames(data):
-    """{(gop, display_index): RGBA} by parsing with the native front end and decoding with the oracle"""
+def oracle_frames(data, detail=None):
+    """{(gop, display_index): RGBA} by parsing with the native front end and decoding with the oracle.  The quantiser
+    matrices are those of the sequence header in force (the reference reloads them at each, decoders/jsv.js:540-558).
+    detail (a dict): filled with {(gop, display_index): the picture's boundary tensors, its planes and the planes it
+    predicted from} -- what explain_mismatch() holds a capture of the pipeline against."""
     import leon_vlc_ctypes as V
     from oracle import oracle_py as O
     st = V.Stream(data, threads=1)
     info = st.info
     cw, ch, fw, fh = info.coded_width, info.coded_height, info.frame_width, info.frame_height
-    qm = np.concatenate([np.frombuffer(bytes(info.intra_qm), np.uint8), np.frombuffer(bytes(info.non_intra_qm), np.uint8)])
+    matrices = lambda i: np.concatenate([np.frombuffer(bytes(i.intra_qm), np.uint8), np.frombuffer(bytes(i.non_intra_qm), np.uint8)])
+    qm = matrices(info)
     out = {}
     gop = -1
     older = newer = None
@@ -36,6 +40,8 @@ def oracle_frames(data):
         p = st.next_picture(dense=True)
         if p is None:
             break
+        if p["new_sequence"]:
+            qm = matrices(st.refresh_info())
         if p["type"] == 1:
             gop += 1
             older = newer = None
@@ -47,6 +53,8 @@ def oracle_frames(data):
         planes = O.decode_picture(p["type"], cw, ch, p["coef_y"], p["coef_cb"], p["coef_cr"], p["qscale"], p["intra"],
                                   repadd=p.get("repadd"), mb_dir=p.get("mb_dir"), mv_fwd=p.get("mv_fwd"), mv_bwd=p.get("mv_bwd"),
                                   qm=qm, ref_fwd=fwd, ref_bwd=bwd, coef_a=p.get("coef_a"))
+        if detail is not None:
+            detail[(gop, p["temporal_reference"])] = {"pic": p, "planes": planes, "fwd": fwd, "bwd": bwd, "qm": qm.copy()}
         if p["type"] != 3:
             older, newer = newer, planes
         n3 = cw * ch * 3 // 2
@@ -66,6 +74,120 @@ def differing_macroblocks(a, b):
     for y, x in zip(*np.nonzero(d)):
         out[(int(y) // 16, int(x) // 16)] = out.get((int(y) // 16, int(x) // 16), 0) + 1
     return sorted((r, c, n) for (r, c), n in out.items())
+
+
+# ---- a wrong frame comes with the inputs that produced it ----------------------------------------------------------------------
+# Round 3 saw B pictures of small pipelines come out wrong in whole macroblocks, late in a process that had freed physically
+# contiguous slot rings (DESIGN.md section 9) -- and had nothing but the frame to look at.  The pipelines of this file run
+# with LEON_DEBUG_CAPTURE (csrc/leon_pipeline_impl.h): after every dependency level the planes each picture wrote and predicted
+# from, after the last one every GOP's device arena (maps, group offsets, entry lists as the kernels left them).  A frame that
+# differs from the oracle's is then explained: which of its inputs held other bytes than the oracle's -- maps, lists, a
+# reference slot -- and the capture is kept under gpurun_out/flake/ (which travels back from the GPU box).  No mismatch:
+# the capture is deleted.
+
+CAPTURE_ROOT = os.path.join(ROOT, "gpurun_out", "capture")
+_capture_no = [0]
+
+
+def start_capture():
+    import shutil
+    _capture_no[0] += 1
+    d = os.path.join(CAPTURE_ROOT, "%d_%d" % (os.getpid(), _capture_no[0]))
+    shutil.rmtree(d, ignore_errors=True)
+    os.makedirs(d)
+    os.environ["LEON_DEBUG_CAPTURE"] = d          # read by leon_pipeline_create*
+    return d
+
+
+def end_capture(d, keep_as=None):
+    import shutil
+    os.environ.pop("LEON_DEBUG_CAPTURE", None)
+    if keep_as and os.path.isdir(d):
+        dst = os.path.join(ROOT, "gpurun_out", "flake", keep_as)
+        shutil.rmtree(dst, ignore_errors=True)
+        os.makedirs(os.path.dirname(dst), exist_ok=True)
+        shutil.move(d, dst)
+        return dst
+    shutil.rmtree(d, ignore_errors=True)
+    return None
+
+
+def read_capture_index(d):
+    """[{'window':, 'lane':, 'gop':, 'tref':, ... offsets ...}], geometry"""
+    pics, geom = [], {}
+    for w in sorted(os.listdir(d)):
+        idx = os.path.join(d, w, "index.txt")
+        if not os.path.exists(idx):
+            continue
+        for line in open(idx):
+            kind, *kv = line.split()
+            rec = dict(x.split("=", 1) for x in kv)
+            if kind == "geom":
+                geom = rec
+            elif kind == "pic":
+                rec = {k: int(v) for k, v in rec.items()}
+                rec["window"] = w
+                pics.append(rec)
+    return pics, geom
+
+
+def explain_mismatch(d, key, detail, got=None, want=None):
+    """text: which inputs of frame `key` = (gop, display index) differ, in the capture `d`, from what the oracle decoded from"""
+    lines = []
+    try:
+        pics, geom = read_capture_index(d)
+        hit = [r for r in pics if (r["gop"], r["tref"]) == tuple(key)]
+        if not hit:
+            return "no capture of frame %s in %s" % (key, d)
+        r, ref = hit[-1], detail[tuple(key)]
+        p = ref["pic"]
+        mbs, ng = int(geom["mbs"]), int(geom["n_groups"])
+        arena = np.fromfile(os.path.join(d, r["window"], "arena_%d.bin" % r["lane"]), np.uint8)
+        lines.append("frame %s: type %d, level %d, window %s lane %d, slots out/fwd/bwd %d/%d/%d, %s parser" %
+                     (key, r["type"], r["level"], r["window"], r["lane"], r["out"], r["fwd"], r["bwd"], "GPU" if geom.get("gpu_parser") == "1" else "host"))
+        if got is not None and want is not None:
+            lines.append("  differing macroblocks (row, col, pixels): %s" % (differing_macroblocks(got, want),))
+        coded = None
+        for name, dt, n in (("qscale", np.uint8, mbs), ("intra", np.uint8, mbs), ("repadd", np.uint8, mbs), ("mb_dir", np.uint8, mbs),
+                            ("mv_fwd", np.int16, 2 * mbs), ("mv_bwd", np.int16, 2 * mbs)):
+            if r[name] < 0 or p.get(name) is None:
+                continue
+            have = arena[r[name]:r[name] + n * np.dtype(dt).itemsize].view(dt)
+            exp = np.asarray(p[name], dt).reshape(-1)
+            bad = np.nonzero(have != exp)[0]
+            if dt == np.int16:
+                bad = np.unique(bad // 2)
+            lines.append("  map %-7s: %d macroblocks differ from the host parser's%s" % (name, len(bad), (" -- " + str(bad[:16].tolist())) if len(bad) else ""))
+        go = arena[r["grp_off"]:r["grp_off"] + 4 * (ng + 1)].view(np.uint32)
+        ego = np.asarray(p["grp_off"], np.uint32)
+        ent = arena[r["entries"]:r["entries"] + 4 * int(go[-1])].view(np.uint32) if go[-1] < (1 << 24) else np.zeros(0, np.uint32)
+        eent = np.asarray(p["entries"], np.uint32)
+        bad_g = [g for g in range(ng) if sorted(ent[go[g]:go[g + 1]].tolist()) != sorted(eent[ego[g]:ego[g + 1]].tolist())]
+        lines.append("  entry lists: %d of %d groups differ from the host parser's (as sets)%s" % (len(bad_g), ng, (" -- " + str(bad_g[:16])) if bad_g else ""))
+        for which in ("fwd", "bwd", "out"):
+            f = os.path.join(d, r["window"], "L%d_g%d_t%d_%s.planes" % (r["level"], r["lane"], r["tref"], which))
+            exp = ref["planes"] if which == "out" else ref[which]
+            if not os.path.exists(f) or exp is None:
+                continue
+            have = np.fromfile(f, np.uint8)
+            n = min(len(have), len(exp))
+            bad = np.nonzero(have[:n] != np.asarray(exp, np.uint8)[:n])[0]
+            lines.append("  %s slot planes after the level: %d of %d bytes differ from the oracle's%s" %
+                         (which, len(bad), n, (" (first at %d, last at %d)" % (bad[0], bad[-1])) if len(bad) else ""))
+    except Exception as e:          # the explanation must never hide the failure it explains
+        lines.append("  (explain_mismatch itself failed: %r)" % (e,))
+    return "\n".join(lines)
+
+
+def assert_frames(got, want, detail, capture, name):
+    """got == want frame by frame; a difference is explained from the capture, which is then kept"""
+    bad = [k for k in sorted(want) if k not in got or got[k].shape != want[k].shape or not np.array_equal(got[k], want[k])]
+    if not bad:
+        end_capture(capture)
+        return
+    text = "\n".join(explain_mismatch(capture, k, detail, got.get(k), want[k]) for k in bad[:3])
+    kept = end_capture(capture, keep_as=name)
+    raise AssertionError("%d frames differ from the oracle: %s\n%s\ncapture kept in %s" % (len(bad), bad[:8], text, kept))
 
 
 def run_pipeline(L, data, **kw):
@@ -194,13 +316,16 @@ def test_frame_widths_that_are_no_multiple_of_8(L, gpu_parser):
     walks the frame with the reference's flat index, see k_rgba_twin)"""
     for data in (open(os.path.join(STREAMS, "ibbp_96x64.jsv"), "rb").read(),
                  ibbp_stream(64, 48, [6, 9, 3], seed=61, frame=(61, 45))):
-        want = oracle_frames(data)
-        got, order, stats = run_pipeline(L, data, parser_threads=2, gops_per_window=2, gpu_parser=gpu_parser)
+        detail = {}
+        want = oracle_frames(data, detail)
+        cap = start_capture()
+        try:
+            got, order, stats = run_pipeline(L, data, parser_threads=2, gops_per_window=2, gpu_parser=gpu_parser)
+        except BaseException:
+            end_capture(cap)
+            raise
         assert set(got) == set(want) and stats["pictures"] == len(want)
-        for k in sorted(want):
-            assert got[k].shape == want[k].shape
-            bad = np.argwhere(got[k] != want[k])
-            assert bad.size == 0, "frame %s differs in %d bytes, first at %s" % (k, len(bad), bad[0])
+        assert_frames(got, want, detail, cap, "frame_widths_%s" % ("gpu" if gpu_parser else "host"))
 
 
 @pytest.mark.parametrize("gpu_parser", [False, True], ids=["host-parser", "gpu-parser"])
@@ -212,9 +337,11 @@ def test_a_stream_that_is_still_arriving(L, gpu_parser):
     import time
     import leon_vlc_ctypes as V
     data = ibbp_stream(96, 64, [6, 9, 3, 12, 6], seed=77)
-    want = oracle_frames(data)
+    detail = {}
+    want = oracle_frames(data, detail)
     offs = V.Stream(data, threads=1).keymap()
     got, lock = {}, threading.Lock()
+    cap = start_capture()
 
     def on_window(window, frames):
         with lock:
@@ -244,11 +371,13 @@ def test_a_stream_that_is_still_arriving(L, gpu_parser):
             if at == len(data):
                 break
         pipe.wait()
+    except BaseException:
+        end_capture(cap)
+        raise
     finally:
         pipe.close()
     assert set(got) == set(want)
-    for k in want:
-        assert np.array_equal(got[k], want[k]), (k, differing_macroblocks(got[k], want[k]))
+    assert_frames(got, want, detail, cap, "still_arriving_%s" % ("gpu" if gpu_parser else "host"))
     # feeding backwards or beyond the end is refused / ignored
     with pytest.raises(L.LeonError):
         L.Pipeline(data, valid_bytes=len(data) + 1)
@@ -273,27 +402,80 @@ def test_pipeline_errors(L):
 
 
 @pytest.mark.parametrize("gpu_parser", [False, True], ids=["host-parser", "gpu-parser"])
-@pytest.mark.parametrize("which", ["intra", "non-intra"])
-def test_a_later_sequence_header_with_other_matrices_is_refused(L, gpu_parser, which):
-    """the pipeline dequantises with the matrices of the stream's first sequence header; every key-map GOP has a
-    sequence header of its own (the reference reloads the matrices at each, decoders/jsv.js:540-558): a GOP whose
-    header carries another matrix ends the run with an error instead of wrong pixels"""
+@pytest.mark.parametrize("which", ["intra", "non-intra", "both"])
+def test_a_later_sequence_header_with_other_matrices_decodes_to_the_oracles_frames(L, gpu_parser, which):
+    """every key-map GOP has a sequence header of its own and the reference reloads both quantiser matrices at each
+    (decoders/jsv.js:540-558): a stream whose GOPs carry DIFFERENT matrices decodes -- every picture with the matrices of
+    its own sequence (leon_add_quant_matrices / leon_picture.qm_set), also when GOPs of different sequences share a window
+    and a launch.  (Round 3 refused such a stream.)"""
     other = (np.arange(64, dtype=np.uint8) + 20)
     other[0] = 8
-    qm = (other, None) if which == "intra" else (None, other)
-    data = ibbp_stream(96, 64, [6, 6, 6], seed=11, gop_qm={1: qm})
+    third = np.full(64, 40, np.uint8)
+    third[0] = 8
+    qm1 = {"intra": (other, None), "non-intra": (None, other), "both": (other, third)}[which]
+    qm3 = {"intra": (third, None), "non-intra": (None, third), "both": (third, other)}[which]
+    data = ibbp_stream(96, 64, [6, 6, 9, 6, 3], seed=11, gop_qm={1: qm1, 3: qm3, 4: qm1})
+    detail = {}
+    want = oracle_frames(data, detail)
+    assert len({d["qm"].tobytes() for d in detail.values()}) == 3          # the oracle really switched matrices
+    plain = oracle_frames(ibbp_stream(96, 64, [6, 6, 9, 6, 3], seed=11))
+    assert any(not np.array_equal(want[k], plain[k]) for k in want if k[0] == 1)      # and they matter to the pixels
+    for window in (1, 4):
+        cap = start_capture()
+        try:
+            got, _, stats = run_pipeline(L, data, parser_threads=2, gops_per_window=window, gpu_parser=gpu_parser, max_gop_pictures=64)
+        except BaseException:
+            end_capture(cap)
+            raise
+        assert set(got) == set(want) and stats["pictures"] == len(want)
+        assert_frames(got, want, detail, cap, "matrices_%s_%d" % (which, window))
+
+
+@pytest.mark.parametrize("gpu_parser", [False, True], ids=["host-parser", "gpu-parser"])
+def test_a_sequence_header_that_changes_the_picture_size_is_refused(L, gpu_parser):
+    """the one thing of a later sequence header the pipeline cannot honour: its rings are made for one size"""
+    import jsv_writer as W
+    import synth as S
+
+    def one_gop(cw, ch, seed):
+        rng = np.random.default_rng(seed)
+        pics = []
+        for ptype, disp, f, b in S.gop_ibbp(6):
+            t = S.make_picture(rng, cw, ch, ptype, force_dir=2 if (ptype == S.PIC_B and f is None) else None)
+            t["display"] = disp
+            pics.append(t)
+        return W.write_stream(pics, cw, ch, cw, ch, gop_starts=[0])[0]
+    data, _ = W.merge_gops([one_gop(96, 64, 1), one_gop(64, 48, 2), one_gop(96, 64, 3)], 96, 64)
     pipe = L.Pipeline(data, gops_per_window=1, parser_threads=1, max_gop_pictures=64, gpu_parser=gpu_parser)
     try:
         with pytest.raises(L.LeonError) as e:
             pipe.wait()
-        assert "sequence header changes the %s quantiser matrix" % which in str(e.value)
+        assert "changes the picture size" in str(e.value)
     finally:
         pipe.close()
-    # the same matrices in EVERY header are fine
-    same = ibbp_stream(96, 64, [6, 6], seed=11, gop_qm={0: qm, 1: qm})
-    want = oracle_frames(same)
-    got, _, _ = run_pipeline(L, same, parser_threads=2, gops_per_window=2, gpu_parser=gpu_parser, max_gop_pictures=64)
+
+
+def test_default_parser_falls_back_to_the_host_beyond_the_gpu_parsers_limits(L, monkeypatch):
+    """a caller who never asked for the GPU parser must not be refused for its limits (group counters beyond
+    LDS, shards of 2^28 bytes): LEON_PIPELINE_PARSER_DEFAULT then decodes on the parser threads, an explicit
+    LEON_PIPELINE_PARSER_GPU keeps its error.  The limit is mocked (LEON_DEBUG_GPU_PARSER_LIMIT = groups per picture)."""
+    data = ibbp_stream(96, 64, [6, 6], seed=5)
+    want = oracle_frames(data)
+    p = L.Pipeline(data, gops_per_window=2, parser_threads=1)
+    try:
+        assert p.info.gpu_parser == 1
+        p.wait()
+    finally:
+        p.close()
+    monkeypatch.setenv("LEON_DEBUG_GPU_PARSER_LIMIT", "4")
+    got, _, _ = run_pipeline(L, data, parser_threads=1, gops_per_window=2, gpu_parser=None)
     assert set(got) == set(want) and all(np.array_equal(got[k], want[k]) for k in want)
+    p = L.Pipeline(data, gops_per_window=2, parser_threads=1, gpu_parser=None)
+    try:
+        assert p.info.gpu_parser == 0
+        p.wait()
+    finally:
+        p.close()
 
 
 @pytest.mark.parametrize("gpu_parser", [False, True], ids=["host-parser", "gpu-parser"])
