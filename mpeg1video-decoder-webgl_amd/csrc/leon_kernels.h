@@ -468,6 +468,9 @@ __device__ __forceinline__ int clamp_med3(int v, int hi)      // min(max(v, 0), 
 // `use` = this lane's macroblock predicts from this reference at all (B pictures: direction map);
 // a lane that does not carries the out-of-range offset: no cache access, zeros come back, and
 // recon_task() replaces the unused predictor by the other one.
+// (The offset of a lane that must not fetch is kOobBit itself, by a select: ADDING the bit to the offset -- tried in round 4
+// to save the select -- is wrong for a lane whose unused vector is garbage: its window column is then anything, and the
+// sum wraps back into the 2 GiB the resource covers: a real load far outside the allocation.)
 __device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, int W, int H, int y,
                                               int px, int ay, int oh, int ov, bool in_pic, bool last_row, bool use)
 {

@@ -41,6 +41,9 @@ typedef uint32_t vlc_u4 __attribute__((ext_vector_type(4)));      // a 16-byte r
 #ifndef LEON_VLC_WAVES
 #define LEON_VLC_WAVES 4
 #endif
+#ifndef LEON_VLC_LOCKSTEP
+#define LEON_VLC_LOCKSTEP 0      // 1: the slice loop as a state machine whose rounds the lanes of a wave run in step (round 4: bit-exact, and slower -- see below); 0: round 3's loop
+#endif
 #ifndef LEON_VLC_TWO_STEPS
 #define LEON_VLC_TWO_STEPS 1
 #endif
@@ -121,9 +124,15 @@ enum { VLC_ERR_MBA = 1, VLC_ERR_ADDR, VLC_ERR_TYPE, VLC_ERR_MOTION, VLC_ERR_CBP,
 
 // Requests dwords [loaded, upto) of a lane's stream into its ring slots: 16 conditional LDS-direct loads, one per
 // slot (the LDS address of such a load is wave-uniform: slot i of every lane that wants it goes in one instruction).
-// NOT inlined: the top-up sits in front of every syntax element (28 places), and 28 copies of this made the kernel
-// four times as long as the instruction cache.
-__device__ __attribute__((noinline)) void vlc_request(const uint32_t* base, uint32_t loaded, uint32_t upto, uint32_t nd, uint32_t* wave_ring, int lane)
+// NOT inlined in the legacy loop: the top-up sits in front of every syntax element (28 places), and 28 copies of this made
+// the kernel four times as long as the instruction cache.  The lockstep loop has ONE top-up per round: inlined there (a call
+// in the middle of the loop costs the callee's register saves in scratch memory).
+#if LEON_VLC_LOCKSTEP
+__device__ __forceinline__ void vlc_request(
+#else
+__device__ __attribute__((noinline)) void vlc_request(
+#endif
+const uint32_t* base, uint32_t loaded, uint32_t upto, uint32_t nd, uint32_t* wave_ring, int lane)
 {
 #pragma unroll
     for (int i = 0; i < 16; i++) {
@@ -185,9 +194,12 @@ struct VlcWin {
     // (requested half a ring ago), then request up to a full ring again.  (Requesting without the wait and waiting only
     // when a lane is about to read what has not been waited for -- so that the wait sees the stores of the last symbols
     // instead of the loads, gfx950 counts both on one counter -- measured no faster.)
-    __device__ __forceinline__ void sync(uint32_t* wave_ring, int lane)
+    // MARGIN: how many dwords [next, next + MARGIN) must have landed afterwards -- the legacy loop takes at most one dword
+    // between two calls (3: take() reads dword next + 1), the lockstep loop up to five in one round (7)
+    template <int MARGIN = 3>
+    __device__ __forceinline__ void sync(uint32_t* wave_ring, int lane, bool live = true)
     {
-        const bool low = loaded - next < 8u || safe - next < 3u;      // take() reads dword next + 1
+        const bool low = live && (loaded - next < (uint32_t)(MARGIN + 5) || safe - next < (uint32_t)MARGIN);
         if (__builtin_amdgcn_ballot_w64(low) != 0) {
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             safe = loaded;
@@ -236,6 +248,7 @@ struct VlcCtx {                  // per lane: the state a slice carries from mac
     int type, full_pel_fwd, fwd_rsize, full_pel_bwd, bwd_rsize;
     uint32_t* wave_ring;         // LDS ring of the wave (VlcWin::sync)
     int lane;
+    uint32_t n_bytes, end_byte;  // lockstep loop: the slice's bounds for the end-of-slice test
 };
 #define VLC_SYNC(r, c) (r).sync((c).wave_ring, (c).lane)
 
@@ -476,6 +489,239 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
     return 0;
 }
 
+#ifndef LEON_VLC_HDR_QUORUM
+#define LEON_VLC_HDR_QUORUM 12
+#endif
+// ---- the slice loop in LOCKSTEP (round 4) -------------------------------------------------------------------------------------
+// Round 3's loop is the host parser's control flow, one lane per slice: decode_macroblock calls a block routine per coded
+// block, each with a coefficient loop of its own -- six inlined copies of the same loop at six places of the program, around
+// them the header code.  A wave executes the union of its lanes' paths: a lane stepping over the symbols of its Cb block and a
+// lane stepping over those of a luma block run the SAME instructions at DIFFERENT addresses, one after the other; a lane that
+// reads a macroblock header stalls 63 lanes that are in coefficients.  Measured: 10.8 of 64 lanes active per vector
+// instruction (profiles/r03d_gpu_parser_sq_counters.txt), 508 k vector instructions per wave and window.
+// Here a lane is a little state machine -- AT A MACROBLOCK BOUNDARY (end-of-slice test, address increment, header) ->
+// AT A BLOCK (which one, DC value / first symbol) -> IN COEFFICIENTS (symbols stepped over, two table lookups a round) --
+// and the wave runs rounds: every round has ONE place for each kind of work, executed by all the lanes that are in that
+// state.  The header section is the long one and the rarest state; it is entered only when a quorum of lanes waits at a
+// macroblock boundary (LEON_VLC_HDR_QUORUM), or when nobody has coefficients left to step over -- the macroblock headers
+// are read in passes of their own, and the coefficient stepping in between runs lanes of like work.
+// Same bits, same tables, same decisions and error conditions as the legacy loop (kept below, LEON_VLC_LOCKSTEP=0, for A/B
+// runs) and as leon_vlc.cpp; tests/test_gpu_parser_gpu.py holds them against each other tensor by tensor.
+enum { VLC_PH_MB = 0, VLC_PH_BLOCK = 1, VLC_PH_COEF = 2, VLC_PH_DONE = 3 };
+
+struct VlcLane {                 // what a lane carries from round to round beside VlcCtx
+    int phase;
+    uint32_t todo;               // blocks of the macroblock still to read: bit (9 - block)
+    int incr;                    // macroblock_address_increment collected so far (escapes), -1: none pending
+    int mba_state;               // 0: stuffing may still come, 1: escapes only (the reference's two loops, jsv.js:737-748)
+    uint32_t start, dcw, gidbq;  // the block being read: first coefficient bit, DC word, group | block of the group << 20
+    int k, n;                    // entries so far, next coefficient position
+    int err;
+};
+
+__device__ __forceinline__ void vlc_after_macroblock(VlcWin& r, const VlcCtx& S, VlcLane& l)
+{
+    // next_bits_are_start_code (decoders/jsv.js:1710-1760): byte aligned 00 00 01, or the end of the data
+    r.fill();
+    const uint32_t i = (r.pos + 7u) >> 3, skip = (0u - r.pos) & 7u;
+    if (i + 2u >= S.n_bytes) { l.phase = VLC_PH_DONE; return; }
+    if ((uint32_t)((r.w << skip) >> 40) == 1u) { l.phase = VLC_PH_DONE; return; }
+    if (i >= S.end_byte) { l.err = VLC_ERR_END; l.phase = VLC_PH_DONE; }      // behind the start code the host found: ran over it
+}
+
+// one round of the macroblock-boundary state: ONE address increment code; when it is the last one (no stuffing, no escape),
+// the rest of the header.  At most 11 + 11 + 4 * 17 + 13 = 103 bits.
+__device__ __forceinline__ void vlc_round_header(VlcWin& r, const VlcLds& L, const VlcGeom& G, VlcCtx& c, VlcLane& l, bool& slice_begin)
+{
+    const int type = c.type, mbsize = G.mbw * G.mbh;
+    VLC_G vlc_u4* const mbrec = reinterpret_cast<VLC_G vlc_u4*>(c.zbase);
+    r.fill();
+    const uint32_t e = L.mba[r.peek(11)];
+    if (e == 0) { l.err = VLC_ERR_MBA; l.phase = VLC_PH_DONE; return; }
+    r.drop((int)(e >> 8));
+    const int t = (int)(e & 0xffu);
+    if (t == 34 && l.mba_state == 0) return;                       // stuffing: the next code next round
+    l.mba_state = 1;
+    if (t == 35) { l.incr += 33; return; }                         // escape
+    int increment = l.incr + t;
+    l.incr = 0;
+    l.mba_state = 0;
+    if (slice_begin) {
+        slice_begin = false;
+        c.mb_addr += increment;
+    } else {
+        if (c.mb_addr + increment >= mbsize) { vlc_after_macroblock(r, c, l); return; }     // the reference's silent return: the loop goes on
+        if (increment > 1) {
+            c.dc_y = c.dc_cr = c.dc_cb = c.dc_a = 128;
+            if (type == 2) { c.fw_h = c.fw_h_prev = 0; c.fw_v = c.fw_v_prev = 0; }
+        }
+        while (increment > 1) {                                    // skipped macroblocks
+            const int a = ++c.mb_addr;
+            mbrec[a] = vlc_u4{(uint32_t)c.prev_dir << 10, vlc_mv_word(c.fw_h, c.fw_v), vlc_mv_word(c.bw_h, c.bw_v), 0u};
+            increment--;
+        }
+        c.mb_addr++;
+    }
+    const int mb = c.mb_addr;
+    if (mb < 0 || mb >= mbsize) { l.err = VLC_ERR_ADDR; l.phase = VLC_PH_DONE; return; }
+    c.mb_col += mb - c.rc_addr;
+    c.rc_addr = mb;
+    while (c.mb_col >= G.mbw) { c.mb_col -= G.mbw; c.mb_row++; }
+    r.fill();
+    const uint32_t te = L.mbtype[type][r.peek(6)];
+    if (te == 0) { l.err = VLC_ERR_TYPE; l.phase = VLC_PH_DONE; return; }
+    r.drop((int)(te >> 8));
+    const int mb_type = (int)(te & 0xffu);
+    c.mb_intra = mb_type & 0x01;
+    const int mot_fw = mb_type & 0x08, mot_bw = mb_type & 0x04;
+    if (mb_type & 0x10) c.qs = (int)r.get(5);
+    if (c.mb_intra) {
+        c.fw_h = c.fw_h_prev = 0; c.fw_v = c.fw_v_prev = 0;
+        c.bw_h = c.bw_h_prev = 0; c.bw_v = c.bw_v_prev = 0;
+        c.prev_dir = 0;
+    } else {
+        c.dc_y = c.dc_cr = c.dc_cb = c.dc_a = 128;
+        int err = 0;
+        if (mot_fw) {
+            c.fw_h_prev = vlc_motion_component(r, L, c.fw_h_prev, c.fwd_rsize, 1 << c.fwd_rsize, err);
+            c.fw_h = c.full_pel_fwd ? c.fw_h_prev * 2 : c.fw_h_prev;
+            c.fw_v_prev = vlc_motion_component(r, L, c.fw_v_prev, c.fwd_rsize, 1 << c.fwd_rsize, err);
+            c.fw_v = c.full_pel_fwd ? c.fw_v_prev * 2 : c.fw_v_prev;
+        } else if (type == 2) {
+            c.fw_h = c.fw_h_prev = 0;
+            c.fw_v = c.fw_v_prev = 0;
+        }
+        if (mot_bw) {
+            c.bw_h_prev = vlc_motion_component(r, L, c.bw_h_prev, c.bwd_rsize, 1 << c.bwd_rsize, err);
+            c.bw_h = c.full_pel_bwd ? c.bw_h_prev * 2 : c.bw_h_prev;
+            c.bw_v_prev = vlc_motion_component(r, L, c.bw_v_prev, c.bwd_rsize, 1 << c.bwd_rsize, err);
+            c.bw_v = c.full_pel_bwd ? c.bw_v_prev * 2 : c.bw_v_prev;
+        }
+        if (err) { l.err = err; l.phase = VLC_PH_DONE; return; }
+        if (type == 3) c.prev_dir = (mot_fw ? 1 : 0) | (mot_bw ? 2 : 0);
+    }
+    mbrec[mb] = vlc_u4{(uint32_t)(c.qs & 0xff) | (c.mb_intra ? (type != 1 ? 0x300u : 0x100u) : (uint32_t)c.prev_dir << 10),
+                      vlc_mv_word(c.fw_h, c.fw_v), vlc_mv_word(c.bw_h, c.bw_v), 0u};
+    int cbp = 0;
+    if (mb_type & 0x02) {
+        r.fill();
+        const uint32_t ce = L.cbp[r.peek(9)];
+        if (ce == 0) { l.err = VLC_ERR_CBP; l.phase = VLC_PH_DONE; return; }
+        r.drop((int)(ce >> 8));
+        cbp = (int)(ce & 0xffu);
+    } else if (c.mb_intra) cbp = 0x3f;
+    int apat = 0;
+    if (G.alpha) apat = c.mb_intra ? 0xf : (int)r.get(4);
+    l.todo = ((uint32_t)cbp << 4) | (uint32_t)apat;                // bit 9 = block 0 ... bit 0 = block 9
+    if (l.todo) l.phase = VLC_PH_BLOCK;
+    else vlc_after_macroblock(r, c, l);
+}
+
+// the block state: which block, where its entries go, its DC value (intra) or its '1s' first symbol.  At most 16 bits.
+__device__ __forceinline__ void vlc_round_block(VlcWin& r, const VlcLds& L, const VlcGeom& G, VlcCtx& c, VlcLane& l)
+{
+    const int block = __builtin_clz(l.todo) - 22;                  // the highest bit of the 10 that is set
+    l.todo &= ~(0x200u >> block);
+    uint32_t gid, bq;
+    if (block < 4 || block >= 6) {                                 // luma, or the A component (blocks 6..9, placed like luma)
+        const int lb = block < 4 ? block : block - 6;
+        const int qb = c.mb_col * 2 + (lb & 1);
+        gid = (uint32_t)((2 * c.mb_row + (lb >> 1)) * G.gy + (qb >> 3)) + (block < 4 ? 0u : (uint32_t)(G.n_y + 2 * G.n_c));
+        bq = (uint32_t)(qb & 7);
+    } else {
+        gid = (uint32_t)(G.n_y + (block == 5 ? G.n_c : 0) + c.mb_row * G.gc + (c.mb_col >> 3));
+        bq = (uint32_t)(c.mb_col & 7);
+    }
+    l.gidbq = gid | (bq << 20);
+    if (c.hdr + kVlcRecWords > c.hdr_end) { l.err = VLC_ERR_SCRATCH; l.phase = VLC_PH_DONE; return; }
+    l.k = 0; l.n = 0; l.dcw = 0u;
+    if (c.mb_intra) {
+        const bool lum = block < 4 || block >= 6;
+        r.fill();
+        const uint32_t e = lum ? L.dc_lum[r.peek(7)] : L.dc_chr[r.peek(8)];
+        if (e == 0) { l.err = VLC_ERR_DC; l.phase = VLC_PH_DONE; return; }
+        r.drop((int)(e >> 8));
+        const int size = (int)(e & 0xffu);
+        // (selects of VALUES, reads and writes alike: a predictor picked through a selected ADDRESS -- what the compiler makes of
+        // conditional stores to different fields -- puts the whole context into scratch memory)
+        const int py = c.dc_y, pcr = c.dc_cr, pcb = c.dc_cb, pa = c.dc_a;
+        const int predictor = block < 4 ? py : block == 4 ? pcr : block == 5 ? pcb : pa;
+        int dc = predictor;
+        if (size > 0) {
+            const int differential = (int)r.get(size);
+            dc = (differential & (1 << (size - 1))) ? predictor + differential
+                                                    : predictor + ((int)(0xffffffffu << size) | (differential + 1));
+        }
+        c.dc_y = block < 4 ? dc : py;
+        c.dc_cr = block == 4 ? dc : pcr;
+        c.dc_cb = block == 5 ? dc : pcb;
+        c.dc_a = block >= 6 ? dc : pa;
+        if ((int16_t)dc != 0) { l.dcw = 0x10000u | (uint32_t)(uint16_t)(int16_t)dc; l.k = 1; }
+        l.n = 1;
+        l.start = r.pos;
+    } else {
+        l.start = r.pos;
+        r.fill();
+        if (r.peek(2) & 2u) { r.drop(2); l.k = 1; l.n = 1; }       // '1s': run 0, level +-1; every other first symbol reads like a later one
+    }
+    l.phase = VLC_PH_COEF;
+}
+
+// the coefficient state: the block's symbols are stepped over (lengths only), two table lookups a round.  At most 28 bits.
+__device__ __forceinline__ void vlc_round_coef(VlcWin& r, const VlcLds& L, VlcCtx& c, VlcLane& l)
+{
+    r.fill();
+    bool eob = false;
+    uint32_t m = L.multi12[(uint32_t)(r.w >> (64 - kVlcMultiBits))];
+    int used = (int)(m & 15u);
+    if (used) {
+        r.drop(used);
+        l.k += (int)((m >> 4) & 7u);
+        l.n += (int)(m >> 8);
+        if (l.n > 64) { l.err = VLC_ERR_INDEX; l.phase = VLC_PH_DONE; return; }
+        eob = (m & 0x80u) != 0u;
+        if (!eob) {      // a second step on the bits that are left (fill() left 33 or more, the first took 12 at most)
+            m = L.multi12[(uint32_t)(r.w >> (64 - kVlcMultiBits))];
+            used = (int)(m & 15u);
+            if (used) {
+                r.drop(used);
+                l.k += (int)((m >> 4) & 7u);
+                l.n += (int)(m >> 8);
+                if (l.n > 64) { l.err = VLC_ERR_INDEX; l.phase = VLC_PH_DONE; return; }
+                eob = (m & 0x80u) != 0u;
+            }
+        }
+    } else {
+        // one symbol: an escape ('0000 01', 20 or 28 bits) or a code of 12 .. 16 bits (seven zeros in front)
+        const uint64_t w = r.w;
+        int used1, run_len;
+        if ((w >> 58) == 1u) {
+            run_len = (int)((w >> 52) & 63);
+            const uint32_t l8 = (uint32_t)(w >> 44) & 255u;
+            used1 = (l8 == 0u || l8 == 128u) ? 28 : 20;
+        } else {
+            if ((w >> 57) != 0u) { l.err = VLC_ERR_COEF; l.phase = VLC_PH_DONE; return; }
+            const uint32_t e = L.long9[(uint32_t)(w >> 48) & 511u];
+            if (e == 0u) { l.err = VLC_ERR_COEF; l.phase = VLC_PH_DONE; return; }
+            run_len = (int)((e >> 5) & 31u);
+            used1 = (int)(e & 31u) + 1;
+        }
+        r.drop(used1);
+        l.n += run_len;
+        if (l.n > 63) { l.err = VLC_ERR_INDEX; l.phase = VLC_PH_DONE; return; }
+        l.n++;
+        l.k++;
+    }
+    if (!eob) return;
+    if (r.pos > (uint32_t)(r.nd << 5)) { l.err = VLC_ERR_END; l.phase = VLC_PH_DONE; return; }     // ran off the data
+    if (l.k) {
+        *reinterpret_cast<VLC_G vlc_u4*>(c.hdr) = vlc_u4{l.start, l.gidbq | (c.mb_intra ? 1u << 23 : 0u) | ((uint32_t)l.k << 24), l.dcw, 0u};
+        c.hdr += kVlcRecWords;
+    }
+    if (l.todo) l.phase = VLC_PH_BLOCK;
+    else { l.phase = VLC_PH_MB; vlc_after_macroblock(r, c, l); }
+}
+
 // LDS (tables 18.4 KB + four rings of 4 KB per workgroup) allows four waves per SIMD: let the registers go that far too
 __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEON_VLC_WAVES, LEON_VLC_WAVES))) void k_vlc_parse(const VlcSlice* __restrict__ slices, uint32_t* __restrict__ slice_words, int n_slices,
                                                    const VlcPic* __restrict__ pics, uint32_t* __restrict__ errors, VlcGeom G,
@@ -519,6 +765,31 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEON_VLC_WA
     }
     bool slice_begin = true;
     int err = 0;
+#if LEON_VLC_LOCKSTEP
+    c.n_bytes = S.n_bytes;
+    c.end_byte = S.end_byte;
+    VlcLane l{};
+    l.phase = VLC_PH_MB;
+    // A wave whose lanes have all finished leaves; a lane without a slice has returned above (the wave's rounds are
+    // decided by ballots over the lanes that are still here).
+    for (;;) {
+        const uint64_t live = __builtin_amdgcn_ballot_w64(l.phase != VLC_PH_DONE);
+        if (live == 0) break;
+        // up to 103 + 16 + 28 bits in a round: five dwords beside the one in hand
+        r.sync<7>(c.wave_ring, c.lane, l.phase != VLC_PH_DONE);
+        const uint64_t at_mb = __builtin_amdgcn_ballot_w64(l.phase == VLC_PH_MB);
+        const uint64_t busy = __builtin_amdgcn_ballot_w64(l.phase == VLC_PH_BLOCK || l.phase == VLC_PH_COEF);
+        // headers in passes of their own: when a quorum waits, or when nobody is left in coefficients
+        if (at_mb != 0 && (busy == 0 || __builtin_popcountll(at_mb) >= LEON_VLC_HDR_QUORUM)) {
+            if (l.phase == VLC_PH_MB) vlc_round_header(r, L, G, c, l, slice_begin);
+        }
+        if (__builtin_amdgcn_ballot_w64(l.phase == VLC_PH_BLOCK) != 0) {
+            if (l.phase == VLC_PH_BLOCK) vlc_round_block(r, L, G, c, l);
+        }
+        if (l.phase == VLC_PH_COEF) vlc_round_coef(r, L, c, l);
+    }
+    err = l.err;
+#else
     for (;;) {
         const int rc = vlc_macroblock(r, L, G, c, slice_begin);       // 1: the reference's silent return, the loop goes on
         if (rc > 1) { err = rc - 1; break; }
@@ -530,6 +801,7 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEON_VLC_WA
         if ((uint32_t)((r.w << skip) >> 40) == 1u) break;
         if (i >= S.end_byte) { err = VLC_ERR_END; break; }    // behind the start code the host found: ran over it
     }
+#endif
     ((VLC_G uint32_t*)slice_words)[j] = (uint32_t)(c.hdr - (VLC_G uint32_t*)S.scratch) / kVlcRecWords;       // coded blocks of the slice
     if (err) atomicCAS(errors + S.pic, 0u, (uint32_t)err | ((uint32_t)S.code << 8));     // rare: a generic atomic is fine here
 }

@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """What a per-window callback costs the end-to-end figure: the timed gpu_parser run of bench.py's end_to_end with and
-without FrameSums (first GOP of every window checksummed on the device), alternating, in one process.
+without bench.run_pipeline_sums (hold_last: the last windows kept and checksummed after the run), alternating, in one process.
   python tools/probe/e2e_ab.py [rounds]"""
 import os
 import sys
@@ -26,5 +26,5 @@ for r in range(int(sys.argv[1]) if len(sys.argv) > 1 else 2):
     st = pipe.stats()
     pipe.close()
     print("empty callback   %.0f pictures/s" % (st["pictures"] / st["seconds"]), flush=True)
-    st, got, n = bench.run_pipeline_sums(L, torch, data, 0, 16, first_gop_only=True, **kw)
-    print("first-GOP sums   %.0f pictures/s (%d frames)" % (st["pictures"] / st["seconds"], n), flush=True)
+    st, got, n = bench.run_pipeline_sums(L, torch, data, 0, 16, hold_last=3, **kw)
+    print("last 3 windows   %.0f pictures/s (%d frames checked after the run)" % (st["pictures"] / st["seconds"], n), flush=True)
