@@ -8,15 +8,15 @@ mkdir -p $out
 B="python3 bench.py --no-cpu-baseline --no-second-recipe"
 S="$B --steps 2 --warmup 1"
 echo "== trace";  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/kt --output-format csv -- $B > $out/kt.log 2>&1 || echo "trace failed"
-echo "== fetch";  timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $out/pf --output-format csv -- $S > $out/pf.log 2>&1 || echo "fetch failed"
-echo "== write";  timeout -k 10 200 rocprofv3 --pmc WRITE_SIZE -d $out/pw --output-format csv -- $S > $out/pw.log 2>&1 || echo "write failed"
-echo "== tcp";    timeout -k 10 200 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -d $out/ptcp --output-format csv -- $S > $out/ptcp.log 2>&1 || echo "tcp failed"
-echo "== valu";   timeout -k 10 200 rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $out/valu --output-format csv -- $S > $out/valu.log 2>&1 || echo "valu failed"
+echo "== fetch";  timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $out/pf --output-format csv -- $S > $out/pf.log 2>&1 || echo "fetch failed"
+echo "== write";  timeout -k 10 400 rocprofv3 --pmc WRITE_SIZE -d $out/pw --output-format csv -- $S > $out/pw.log 2>&1 || echo "write failed"
+echo "== tcp";    timeout -k 10 400 rocprofv3 --pmc TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum -d $out/ptcp --output-format csv -- $S > $out/ptcp.log 2>&1 || echo "tcp failed"
+echo "== valu";   timeout -k 10 400 rocprofv3 --pmc SQ_INSTS_VALU GRBM_GUI_ACTIVE SQ_WAVES SQ_ACTIVE_INST_VALU SQ_BUSY_CYCLES -d $out/valu --output-format csv -- $S > $out/valu.log 2>&1 || echo "valu failed"
 # the memory pipe, 2-3 counters per pass (more "exceeds the capabilities of the hardware to collect")
 i=0
 [ -n "$LEON_MEMPIPE" ] && for c in "TA_TA_BUSY_sum TA_ADDR_STALLED_BY_TC_CYCLES_sum GRBM_GUI_ACTIVE" "TA_DATA_STALLED_BY_TC_CYCLES_sum TA_BUFFER_WRITE_WAVEFRONTS_sum" \
          "TCP_PENDING_STALL_CYCLES_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TCC_WRITE_REQ_sum" "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum TCC_EA0_WRREQ_STALL_sum"; do
-  i=$((i+1)); timeout -k 10 200 rocprofv3 --pmc $c -d $out/mp$i --output-format csv -- $S --unique 2 > $out/mp$i.log 2>&1 || echo "memory-pipe pass $i failed"
+  i=$((i+1)); timeout -k 10 400 rocprofv3 --pmc $c -d $out/mp$i --output-format csv -- $S --unique 2 > $out/mp$i.log 2>&1 || echo "memory-pipe pass $i failed"
 done
 # condense on the box (the raw CSVs of a round exceed what gpurun copies back) and drop the raw output
 tag=${2:-round}
@@ -27,8 +27,8 @@ rm -rf $out/kt $out/pf $out/pw $out/ptcp $out/valu $out/mp1 $out/mp2 $out/mp3 $o
 # the calibration of FETCH_SIZE for this kernel's load shapes (tools/summarize_calibration.py)
 if [ -n "$LEON_CALIBRATE" ]; then
 echo "== calibration"; ./tools/probe/fetch_calib.bin > $out/calib_plain.json
-timeout -k 10 200 rocprofv3 --pmc FETCH_SIZE -d $out/cal_fetch --output-format csv -- ./tools/probe/fetch_calib.bin > $out/cal_fetch.log 2>&1
-timeout -k 10 200 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum -d $out/cal_raw --output-format csv -- ./tools/probe/fetch_calib.bin > $out/cal_raw.log 2>&1
+timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $out/cal_fetch --output-format csv -- ./tools/probe/fetch_calib.bin > $out/cal_fetch.log 2>&1
+timeout -k 10 400 rocprofv3 --pmc TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_BUBBLE_sum -d $out/cal_raw --output-format csv -- ./tools/probe/fetch_calib.bin > $out/cal_raw.log 2>&1
 fi
 timeout -k 10 400 python bench.py > $out/summary/${tag}_bench_line.json 2> $out/bench.err; echo "bench rc=$?"
 echo done
