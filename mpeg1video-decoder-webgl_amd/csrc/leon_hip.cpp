@@ -131,6 +131,7 @@ struct leon_decoder {
     size_t plane_bytes = 0;      // cw*ch*3/2
     size_t slot_stride = 0;      // padded
     uint8_t* d_slots = nullptr;
+    void* d_slots_alloc = nullptr;     // what big_alloc returned (d_slots may start inside it: LEON_SLOT_ALIGN / LEON_SLOT_SKEW)
     std::vector<uint8_t> inuse;
     // batch independence check (check_batch): which picture of the current batch writes a slot
     std::vector<uint32_t> writer_epoch;
@@ -682,7 +683,13 @@ int leon_create(const leon_config* cfg, leon_decoder** out)
         leon_destroy(d);
         return fail(LEON_ERR_NOMEM, "%s", msg.c_str());
     };
-    if (big_alloc((void**)&d->d_slots, d->slot_stride * (size_t)cfg->n_slots + 256, kBigSlots, nullptr, cfg->contiguous_slots == 1) != hipSuccess) return bail("slot ring");
+    // LEON_SLOT_ALIGN / LEON_SLOT_SKEW (bytes; placement experiments, tools/probe/placement_probe.py): the ring starts at a multiple
+    // of ALIGN plus SKEW inside a larger allocation
+    const size_t s_align = getenv("LEON_SLOT_ALIGN") ? (size_t)atoll(getenv("LEON_SLOT_ALIGN")) : 0, s_skew = getenv("LEON_SLOT_SKEW") ? (size_t)atoll(getenv("LEON_SLOT_SKEW")) : 0;
+    if (big_alloc((void**)&d->d_slots_alloc, d->slot_stride * (size_t)cfg->n_slots + 256 + s_align + s_skew, kBigSlots, nullptr, cfg->contiguous_slots == 1) != hipSuccess) return bail("slot ring");
+    d->d_slots = (uint8_t*)d->d_slots_alloc;
+    if (s_align) d->d_slots = (uint8_t*)(((uintptr_t)d->d_slots + s_align - 1) / s_align * s_align);
+    d->d_slots += s_skew;
     if (hipMemsetAsync(d->d_slots, 0, d->slot_stride * (size_t)cfg->n_slots + 256, d->stream) != hipSuccess) return bail("slot memset");
     if (hipMalloc(&d->d_tables, sizeof(Tables)) != hipSuccess) return bail("tables");
     memcpy(d->qm, kDefaultIntra, 64);
@@ -722,7 +729,7 @@ void leon_destroy(leon_decoder* d)
         if (s.host) hipHostFree(s.host);
         if (s.done) hipEventDestroy(s.done);
     }
-    if (d->d_slots) big_free(d->d_slots);          // a contiguous ring goes back to the process's pool, never to the driver (big_alloc)
+    if (d->d_slots_alloc) big_free(d->d_slots_alloc);          // a contiguous ring goes back to the process's pool, never to the driver (big_alloc)
     if (d->d_tables) hipFree(d->d_tables);
     if (d->d_qsets) hipFree(d->d_qsets);
     if (d->h_qsets) hipHostFree(d->h_qsets);
