@@ -103,6 +103,27 @@ def redraw_slots():
 
 
 measure("start")
+if "--many-rings" in sys.argv:
+    # ring after ring, every one HELD (so every one is a new range): step time against the ring's address
+    held = []
+    os.environ.pop("LEON_SLOT_ALIGN", None)
+    os.environ.pop("LEON_SLOT_SKEW", None)
+    for k in range(7):
+        old = wl.dec
+        for b in wl.batches:
+            old.batch_destroy(b)
+        held.append(old)
+        wl.dec = new_decoder()
+        wl.batches = [wl.build_level(li) for li in range(len(wl.levels))]
+        measure("ring %d" % (k + 1))
+    # and back to the first one
+    for b in wl.batches:
+        wl.dec.batch_destroy(b)
+    held.append(wl.dec)
+    wl.dec = held[0]
+    wl.batches = [wl.build_level(li) for li in range(len(wl.levels))]
+    measure("ring 0 again")
+    rounds = 0
 if "--slot-skews" in sys.argv:
     # the slot ring at chosen positions relative to a 64 MiB boundary, everything else held where it is
     for skew in [0, 2, 8, 10, 16, 32, 0, 10, 34, 1, 0]:
