@@ -225,6 +225,16 @@ void upload_tables(leon_decoder* d)
     memcpy(d->h_tables.rgba_lut, kLeonRgbaLut, sizeof(kLeonRgbaLut));
 }
 
+inline bool alpha_geom(const leon_decoder* d) { return d->geom.alpha != 0; }
+// Occupancy of the fused display kernels, set through extra dynamic LDS per workgroup (0 = what registers and LDS allow: 8 workgroups
+// of 4 waves per CU, 7 for B).  Round 4, one box, per type (tools/ab_run.py tree@LEON_LDS_PAD_I=...): the I and the P launches are
+// FASTER with fewer waves in flight -- I 0.477 ms at 8 workgroups per CU, 0.465 at 6, 0.458 at 5 and at 4, 0.630 at 3; P 0.581 /
+// 0.572 / 0.557 / 0.557 / 0.737 -- they wait for the memory pipe, not for instructions, and 32 waves per CU streaming through ~12 regions
+// each get in each other's way in L2 (dense boundary; the SPARSE kernels keep their occupancy: in the pipeline they share the CUs with
+// the parser's 35 KB workgroups, and padded they cost it 8-10 % end to end); the B launches (bound by their instruction count) are indifferent between 7 and 6 (1.045 / 1.038
+// ms) and lose 7 % at 5.  So: I and P at 5 workgroups per CU (20 KB + 11.5 KB of LDS per workgroup), B as the registers allow.
+constexpr size_t kOccupancyPadI = 11776, kOccupancyPadP = 11776, kOccupancyPadB = 0;
+
 int n_groups_of(const Geom& G) { return 2 * G.tasksY + 2 * G.tasksC + (G.alpha ? 2 * G.tasksY : 0); }
 
 // Algorithmic bytes of one picture's reconstruction (dense boundary) from its own maps.  Maps in
@@ -363,7 +373,12 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
     static_assert(64 * kWavesPerWG <= kReconMaxThreads, "k_recon is launched with more threads than its __launch_bounds__");
     const dim3 grid(G.n_wg), block(64 * kWavesPerWG);
     // LEON_DEBUG_LDS_PAD (bytes): extra dynamic LDS per workgroup = an occupancy throttle for experiments
-    static const size_t lds_pad = getenv("LEON_DEBUG_LDS_PAD") ? (size_t)atol(getenv("LEON_DEBUG_LDS_PAD")) : 0;
+    static const size_t lds_pad_all = getenv("LEON_DEBUG_LDS_PAD") ? (size_t)atol(getenv("LEON_DEBUG_LDS_PAD")) : 0;
+    // per picture type (experiments): LEON_LDS_PAD_I / _P / _B
+    static const size_t lds_pad_t[3] = {getenv("LEON_LDS_PAD_I") ? (size_t)atol(getenv("LEON_LDS_PAD_I")) : kOccupancyPadI,
+                                        getenv("LEON_LDS_PAD_P") ? (size_t)atol(getenv("LEON_LDS_PAD_P")) : kOccupancyPadP,
+                                        getenv("LEON_LDS_PAD_B") ? (size_t)atol(getenv("LEON_LDS_PAD_B")) : kOccupancyPadB};
+    const size_t lds_pad = lds_pad_all + (display && !sparse && !alpha_geom(d) ? lds_pad_t[type - 1] : 0);
     const bool alpha = d->geom.alpha != 0;
     const size_t lds = kWavesPerWG * (display ? (alpha ? kLdsPerWaveDisplayAlpha : kLdsPerWaveDisplay) : kLdsPerWave) + lds_pad;      // display kernels: + kLdsLut of static LDS (the conversion tables)
     if (display && alpha) {          // yuva: the A parts ride in the same task (k_recon_display<.., .., true>)
