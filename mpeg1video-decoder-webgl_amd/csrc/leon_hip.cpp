@@ -348,9 +348,15 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
 {
     Geom G = d->geom;
     G.n_pics = n;
+    const bool alpha = d->geom.alpha != 0;
+    const bool pair = LEON_PAIR_LUMA && LEON_CARRY && display && !sparse && !alpha && type != LEON_PIC_I;      // k_recon_display: recon_luma_pair, two tiles
+    // waves per workgroup: 4 -- but 6 for the dense B display kernel, whose two tiles per wave would leave room for 5 workgroups of 4
+    // per CU (20 waves: it loses 7 % there) and leave room for 4 of 6 (24 waves, what its registers allow anyway); LEON_WAVES_B (experiments)
+    static const int waves_b = getenv("LEON_WAVES_B") ? atoi(getenv("LEON_WAVES_B")) : kWavesPerWGPairB;      // (6 measured: +5 % on the B launches; 4 it is)
+    const int wpw = pair && type == LEON_PIC_B && waves_b >= 1 && waves_b * 64 <= kReconMaxThreads ? waves_b : kWavesPerWG;
     if (display) {   // one task = one chroma group with everything above it (k_recon_display)
         G.tasks_per_pic = G.tasksC;
-        G.wg_per_pic = (G.tasks_per_pic + kWavesPerWG - 1) / kWavesPerWG;
+        G.wg_per_pic = (G.tasks_per_pic + wpw - 1) / wpw;
         G.inv_wg_per_pic = G.wg_per_pic == 1 ? 0u : (uint32_t)(((1ull << 32) + G.wg_per_pic - 1) / G.wg_per_pic);
     }
     // B launches: the workgroups of two consecutive pictures alternate (pic_of_wg), an odd last picture leaves its partner's idle
@@ -370,8 +376,8 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
             tl.bytes += 4.0 * (double)entries + 4.0 * (double)(n_groups_of(d->geom) + 1) * n - 768.0 * (double)tl.mbs;
         HIP_TRY(hipEventRecord(tl.a, d->stream));
     }
-    static_assert(64 * kWavesPerWG <= kReconMaxThreads, "k_recon is launched with more threads than its __launch_bounds__");
-    const dim3 grid(G.n_wg), block(64 * kWavesPerWG);
+    static_assert(64 * kWavesPerWG <= kReconMaxThreads && 64 * kWavesPerWGPairB <= kReconMaxThreads, "k_recon is launched with more threads than its __launch_bounds__");
+    const dim3 grid(G.n_wg), block(64 * wpw);
     // LEON_DEBUG_LDS_PAD (bytes): extra dynamic LDS per workgroup = an occupancy throttle for experiments
     static const size_t lds_pad_all = getenv("LEON_DEBUG_LDS_PAD") ? (size_t)atol(getenv("LEON_DEBUG_LDS_PAD")) : 0;
     // per picture type (experiments): LEON_LDS_PAD_I / _P / _B
@@ -379,8 +385,10 @@ int launch_recon_type(leon_decoder* d, int type, const PicDesc* d_descs, int n, 
                                         getenv("LEON_LDS_PAD_P") ? (size_t)atol(getenv("LEON_LDS_PAD_P")) : kOccupancyPadP,
                                         getenv("LEON_LDS_PAD_B") ? (size_t)atol(getenv("LEON_LDS_PAD_B")) : kOccupancyPadB};
     const size_t lds_pad = lds_pad_all + (display && !sparse && !alpha_geom(d) ? lds_pad_t[type - 1] : 0);
-    const bool alpha = d->geom.alpha != 0;
-    const size_t lds = kWavesPerWG * (display ? (alpha ? kLdsPerWaveDisplayAlpha : kLdsPerWaveDisplay) : kLdsPerWave) + lds_pad;      // display kernels: + kLdsLut of static LDS (the conversion tables)
+    // the two-tile kernels (26.25 KB per workgroup = six per CU): P back to five (LEON_LDS_PAD_PP / _BP: experiments)
+    static const size_t lds_pad_ppair = getenv("LEON_LDS_PAD_PP") ? (size_t)atol(getenv("LEON_LDS_PAD_PP")) : 1024;
+    static const size_t lds_pad_bpair = getenv("LEON_LDS_PAD_BP") ? (size_t)atol(getenv("LEON_LDS_PAD_BP")) : 0;
+    const size_t lds = (size_t)wpw * (display ? (alpha ? kLdsPerWaveDisplayAlpha : (pair ? kLdsPerWaveDisplayPair : kLdsPerWaveDisplay)) : kLdsPerWave) + (pair ? lds_pad_all + (type == LEON_PIC_P ? lds_pad_ppair : lds_pad_bpair) : lds_pad);      // display kernels: + kLdsLut of static LDS (the conversion tables)
     if (display && alpha) {          // yuva: the A parts ride in the same task (k_recon_display<.., .., true>)
         if (!sparse) {
             if (type == LEON_PIC_I) hipLaunchKernelGGL((k_recon_display<1, false, true>), grid, block, lds, d->stream, d_descs, G, d->d_tables);

@@ -98,7 +98,8 @@ static constexpr int kWavesPerWG = 4;
 // Launch block sizes and the kernels' __launch_bounds__ come from the same constants: a launch with
 // more threads than the bound fails at launch time ("unspecified launch failure" from
 // hipGetLastError -- what a 512-thread block-size sweep of the RGBA kernels ran into in round 1).
-static constexpr int kReconMaxThreads = 256;
+static constexpr int kReconMaxThreads = 384;
+static constexpr int kWavesPerWGPairB = 4;       // (6 waves per workgroup for the dense B display kernel were tried: launch_recon_type)
 static constexpr int kRgbaBlock = 256;
 // A wave's LDS strip.  The tile holds BOTH block groups of a task, [half][row][block][column] int16, and is
 // worked on in place: coefficients -> (column pass) the int16 hand-off values w -> (row pass reads them).
@@ -121,6 +122,24 @@ static constexpr int kLdsPerWaveDisplay = kOffStash + kLdsStash;      // 3840: 4
 static constexpr int kLdsLut = 1280 * 4;         // display kernels: Tables::rgba_lut, one copy per workgroup, in front of the waves' strips
 static constexpr int kLutShift = 21;             // = LEON_RGBA_LUT_SHIFT (static_assert in leon_hip.cpp)
 static constexpr int kLdsPerWaveDisplayAlpha = kLdsPerWaveDisplay + 1024;   // yuva: + the parked A samples of a luma part
+// dense P / B display tasks (round 4): the two luma parts of a task share ONE liveness scan and ONE column pass -- the right part's
+// tile lies behind the wave's strip
+// The wave's strip, two layouts:
+//   0 (all kernels but the next): [tile 2048 | tables 192 + carried vectors 64 | column ids / Y park 512 | stash 1024 (| A park)]
+//   1 (dense P / B display, two tiles): [tile L 2048 | carried vectors 64 | column ids 256 | stash 1024 | tile R 2048] = 5440 bytes:
+//     4 waves + the conversion tables = 26.25 KB, SIX workgroups per CU (with layout 0 plus a second tile: 28 KB, five -- and the B
+//     kernel loses 7 % at five).  What went: the wave's LDS copy of the quantiser tables (the column pass reads its two 8-byte columns
+//     from the picture's QTables in memory: 256 bytes that every wave of the launch reads, L1 hits), and the Y park, which now lies in
+//     the tile half whose row pass has just read it out.
+template <int LAYOUT> struct Lay;
+template <> struct Lay<0> { static constexpr int carry = kOffQtab + 192, slots = kOffSlots, stash = kOffStash; static constexpr bool tables_in_lds = true, park_in_tile = false; };
+template <> struct Lay<1> { static constexpr int carry = kLdsTile, slots = kLdsTile + 64, stash = kLdsTile + 64 + 256, tile_r = kLdsTile + 64 + 256 + kLdsStash;
+                            static constexpr bool tables_in_lds = false, park_in_tile = true; };
+static constexpr int kLdsPerWaveDisplayPair = Lay<1>::tile_r + kLdsTile;      // 5440
+static constexpr int kOffTileR = Lay<1>::tile_r;
+#ifndef LEON_PAIR_LUMA
+#define LEON_PAIR_LUMA 1
+#endif
 
 // ---- small helpers -----------------------------------------------------------
 
@@ -655,6 +674,107 @@ __device__ __forceinline__ void display_half(const PicDesc& pd, const Geom& G, c
     __builtin_amdgcn_raw_buffer_store_b128(pb, rrs, (int)(((row_off + (uint32_t)G.fw) * 4u) | (in_b ? 0u : kOobBit)), 0, 0);
 }
 
+// ---- stage 2 as functions: the liveness scan of a tile and the column pass over a list of live columns ------------------------
+// A column id: tile << 7 | half << 6 | c << 3 | b.  scan_tile: lane (c = hi3, b = lo3) looks at its own column of each half of
+// `tile`; the live lanes queue up behind the n_before ids that are in the list already.  Returns the new length.
+__device__ __forceinline__ uint32_t scan_tile(const char* tile, char* ids, int lane, uint32_t tag, uint32_t n_before, uint64_t (&live)[2])
+{
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const char* cp = tile + h * kLdsHalf + lo3 * 16 + hi3 * 2;
+        uint32_t o = 0;
+#pragma unroll
+        for (int i = 0; i < 8; i++) o |= *reinterpret_cast<const uint16_t*>(cp + i * 128);
+        live[h] = lanes_nonzero((int)o);
+        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(live[h] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live[h], n_before));
+        if (o != 0u) *reinterpret_cast<uint8_t*>(ids + pos) = (uint8_t)(tag + (uint32_t)lane + 64u * h);
+        n_before += (uint32_t)__builtin_popcountll(live[h]);
+    }
+    return n_before;
+}
+
+// The column pass (COL_INT_3 / COL_INT_5, decoders/shaders/mpeg1video.js:19-24) over the n_cols live columns listed in `ids`:
+// lane k takes the k-th; the results replace the coefficients in place.  PAIR: ids may name the second tile (tile0 + tile_step),
+// whose blocks' quantiser scale and intra flag sit in qia1 (lane b: block b's) as the first tile's in qia0.
+// TLDS: the tables are the wave's LDS copy at `qtab`; else `qtab` is the picture's QTables in memory.
+template <bool PAIR, bool TLDS = true>
+__device__ __forceinline__ void column_pass(char* tile0, uint32_t tile_step, const char* ids, const char* qtab, uint32_t n_cols, int qia0, int qia1, int lane)
+{
+    // the clamp bounds live in registers (v_med3 takes no literals on gfx950, and the compiler would
+    // otherwise re-materialise them in front of every use): one scalar, one vector -- a VOP3
+    // instruction may read one scalar register
+    int lo2048 = -2048, hi2047 = 2047;
+    asm("" : "+s"(lo2048), "+v"(hi2047));
+#pragma unroll 1
+    for (uint32_t base = 0; base < n_cols; base += 64u) {             // wave-uniform: once, twice for busy I pictures
+        const uint32_t k = base + (uint32_t)lane;
+        const bool act = k < n_cols;
+        uint32_t id = *reinterpret_cast<const uint8_t*>(ids + k);
+        id = act ? id : 0u;                               // idle lanes redo column 0 and write nothing
+        char* colp = tile0 + ((id & 0x47u) << 4) + ((id >> 2) & 14u);
+        if constexpr (PAIR) colp += (id >> 7) * tile_step;
+        int X[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) X[i] = *reinterpret_cast<const short*>(colp + i * 128);
+        int bq = __builtin_amdgcn_ds_bpermute((int)((id & 7u) << 2), qia0);      // lane b holds block b's macroblock
+        if constexpr (PAIR) {
+            const int bq1 = __builtin_amdgcn_ds_bpermute((int)((id & 7u) << 2), qia1);
+            bq = (id & 128u) ? bq1 : bq;
+        }
+        const bool bia = bq >= 256;
+        const uint32_t qv = (uint32_t)bq & 31u;
+        v2u msel, pm8;                                                               // column c of the tables
+        if constexpr (TLDS) {
+            const char* const qt = qtab + (id & 56u);
+            msel = *reinterpret_cast<const v2u*>(qt + (bia ? 0 : 64));
+            pm8 = *reinterpret_cast<const v2u*>(qt + 128);
+        } else {
+            const uint32_t qo = (id & 56u) + (bia ? 0u : 64u);
+            msel = ldg<v2u>(gptr(qtab), qo);
+            pm8 = ldg<v2u>(gptr(qtab), (id & 56u) + 128u);
+        }
+        int nim = bia ? 0 : -1;
+        asm("" : "+v"(nim));                              // keep it a mask (v_and), not a select
+        const bool dc_lane = bia && (id & 56u) == 0u;
+        uint64_t nz[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) nz[i] = lanes_nonzero(X[i]);
+        const int dc = X[0];
+        int rows_live = 1;                                // wave-uniform: 1 + highest row with a non-zero
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            // a row whose coefficients are zero in every column of the pass costs its compare and a scalar
+            // branch; in a live row every lane runs the branch-free form (zeros stay zero)
+            if (nz[i] != 0) {
+                rows_live = i + 1;
+                int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
+                const int qO = (int)__umul24(qv, ((i < 4 ? msel.x : msel.y) >> (8 * (i & 3))) & 255u);   // quantiser_scale * Q[i][c] < 2^13
+                X[i] = dequant_any(X[i], qO, P, nim, lo2048, hi2047);
+            }
+        }
+        if (dc_lane) X[0] = dc * 256;                     // COL_4 / COL_INT_31
+        const ColOut co = butterfly8_col(X, rows_live);
+        // floor( float(v) * _y ): the int16 the reference hands from pass 1 to pass 2
+        const v2f k04 = {0.4f, 0.4f};
+        const v2f s07 = co.p07 * k04, s16 = co.p16 * k04, s52 = co.p52 * k04, s43 = co.p43 * k04;
+        // floor and conversion in one instruction (v_cvt_flr_i32_f32)
+        int wi[8] = {cvt_floor(s07.x), cvt_floor(s16.x), cvt_floor(s52.y), cvt_floor(s43.y),
+                     cvt_floor(s43.x), cvt_floor(s52.x), cvt_floor(s16.y), cvt_floor(s07.y)};
+        // |s| < 32768 for all eight: every floor(s) is an int16 as it stands
+        const float mx = fmaxf(fmaxf(fmaxf(fabsf(s07.x), fabsf(s16.x)), fmaxf(fabsf(s52.y), fabsf(s43.y))),
+                               fmaxf(fmaxf(fabsf(s43.x), fabsf(s52.x)), fmaxf(fabsf(s16.y), fabsf(s07.y))));
+        if (mx >= 32768.0f) {                             // outside any real stream: int16 wrap / saturation
+#pragma unroll
+            for (int n = 0; n < 8; n++) wi[n] = handoff16(wi[n]);
+        }
+        if (act) {
+#pragma unroll
+            for (int n = 0; n < 8; n++) *reinterpret_cast<short*>(colp + n * 128) = (short)wi[n];
+        }
+    }
+}
+
 // `alpha` (wave-uniform, luma-shaped tasks only): the task reconstructs the A plane of a yuva picture --
 // the same code path as luma with its own coefficient plane, the plane behind Cr in every slot, and the
 // alpha groups of the sparse lists.
@@ -664,9 +784,13 @@ __device__ __forceinline__ void display_half(const PicDesc& pd, const Geom& G, c
 // in front of their reference fetches.  0: a task on its own loads what it needs.
 struct MbCarry { uint32_t flags; };       // q | intra << 8 | repadd >= 128 << 9 | direction << 10 (the vectors: LDS, kOffCarry)
 
-template <int TYPE, bool CHROMA, bool SPARSE, bool DISPLAY, int AMODE = 0, int CARRY = 0>
-__device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int Rt, int g, char* lds, int lane, Display dsp, MbCarry& carry, bool alpha = false)
+// BACK (dense display tasks whose two luma parts share their front, recon_luma_pair): the part's coefficients are in `tile` and have
+// been through the column pass already; `live_in` says which of its columns were live
+template <int TYPE, bool CHROMA, bool SPARSE, bool DISPLAY, int AMODE = 0, int CARRY = 0, bool BACK = false, int LAYOUT = 0>
+__device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int Rt, int g, char* lds, int lane, Display dsp, MbCarry& carry, bool alpha = false,
+                                           char* tile_in = nullptr, uint64_t live_in0 = 0, uint64_t live_in1 = 0)
 {
+    char* const tile = BACK ? tile_in : lds;
     const int W = CHROMA ? G.cw >> 1 : G.cw;
     const int H = CHROMA ? G.ch >> 1 : G.ch;
     const int bw = W >> 3;
@@ -711,7 +835,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
             ent_first[h] = (uint32_t)__builtin_amdgcn_raw_buffer_load_b32(
                 ent_rs, (int)(((s0 + (uint32_t)lane) * 4u) | ((uint32_t)lane < ent_count[h] ? 0u : kOobBit)), 0, kAuxStreamOnce);
         }
-    } else {
+    } else if constexpr (!BACK) {
         // the previous task of this wave may still be reading the tile
         wait_lds_all();
         __builtin_amdgcn_wave_barrier();
@@ -726,8 +850,8 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
         flags = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)carry.flags);
         // the vectors wait in LDS (the 64 bytes behind the staged tables: kOffCarry) -- carried in registers like the
         // flags, the three words went to scratch memory in the B kernel (12 bytes per lane: +6 % HBM traffic per launch)
-        if (TYPE != 1) mf = *reinterpret_cast<const uint32_t*>(lds + kOffCarry + src);
-        if (TYPE == 3) mk = *reinterpret_cast<const uint32_t*>(lds + kOffCarry + 32 + src);
+        if (TYPE != 1) mf = *reinterpret_cast<const uint32_t*>(lds + Lay<LAYOUT>::carry + src);
+        if (TYPE == 3) mk = *reinterpret_cast<const uint32_t*>(lds + Lay<LAYOUT>::carry + 32 + src);
     } else {
         flags = (uint32_t)(ldg<uint8_t>(gptr(pd.qscale), mb) & 31) | (ldg<uint8_t>(gptr(pd.intra), mb) != 0 ? 256u : 0u);   // I pictures honour the intra map too (COL_3)
         if (TYPE != 1) {
@@ -740,8 +864,8 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
         }
         if constexpr (CARRY == 1) {       // lane i < 8 holds macroblock i of the task (and so does every lane i + 8 k)
             carry.flags = flags;
-            if (TYPE != 1) *reinterpret_cast<uint32_t*>(lds + kOffCarry + ((lane & 7) << 2)) = mf;
-            if (TYPE == 3) *reinterpret_cast<uint32_t*>(lds + kOffCarry + 32 + ((lane & 7) << 2)) = mk;
+            if (TYPE != 1) *reinterpret_cast<uint32_t*>(lds + Lay<LAYOUT>::carry + ((lane & 7) << 2)) = mf;
+            if (TYPE == 3) *reinterpret_cast<uint32_t*>(lds + Lay<LAYOUT>::carry + 32 + ((lane & 7) << 2)) = mk;
         }
     }
     const int q = (int)(flags & 31u);
@@ -795,7 +919,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
     const bool any_f = TYPE != 3 || __builtin_amdgcn_ballot_w64(useA) != 0;
     const bool any_b = TYPE == 3 && __builtin_amdgcn_ballot_w64(useB) != 0;
     // the coefficient rows (requested before the maps the reference fetches wait for anyway) have landed
-    if constexpr (!SPARSE) wait_vmem_all();
+    if constexpr (!SPARSE && !BACK) wait_vmem_all();
     if (TYPE != 1) {
 #pragma unroll
         for (int h = 0; h < 2; h++) {
@@ -838,87 +962,18 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
     // the lanes first find the live ones -- lane (c = hi3, b = lo3) looks at its own column of each half --
     // and the wave then runs the pass on them alone, usually in one go for both halves instead of one go
     // per half with most lanes computing zeros.  The results replace the coefficients in place.
-    uint64_t live[2];
-#pragma unroll
-    for (int h = 0; h < 2; h++) {
-        const char* cp = lds + h * kLdsHalf + lo3 * 16 + hi3 * 2;
-        uint32_t o = 0;
-#pragma unroll
-        for (int i = 0; i < 8; i++) o |= *reinterpret_cast<const uint16_t*>(cp + i * 128);
-        live[h] = lanes_nonzero((int)o);
-        // the live lanes queue up: position = live lanes below (of half 0: all of them come first)
-        const uint32_t below = h == 0 ? 0u : (uint32_t)__builtin_popcountll(live[0]);
-        const uint32_t pos = __builtin_amdgcn_mbcnt_hi((uint32_t)(live[h] >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)live[h], below));
-        if (o != 0u) *reinterpret_cast<uint8_t*>(lds + kOffSlots + pos) = (uint8_t)(lane + 64 * h);
+    uint64_t live[2] = {live_in0, live_in1};
+    if constexpr (!BACK) {
+        const uint32_t n_cols = scan_tile(tile, lds + Lay<LAYOUT>::slots, lane, 0u, 0u, live);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        column_pass<false, Lay<LAYOUT>::tables_in_lds>(tile, 0u, lds + Lay<LAYOUT>::slots, Lay<LAYOUT>::tables_in_lds ? lds + kOffQtab : reinterpret_cast<const char*>(pd.qt),
+                                                       n_cols, qia, qia, lane);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     }
-    const uint32_t n_cols = (uint32_t)__builtin_popcountll(live[0]) + (uint32_t)__builtin_popcountll(live[1]);
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    // the clamp bounds live in registers (v_med3 takes no literals on gfx950, and the compiler would
-    // otherwise re-materialise them in front of every use): one scalar, one vector -- a VOP3
-    // instruction may read one scalar register
-    int lo2048 = -2048, hi2047 = 2047;
-    asm("" : "+s"(lo2048), "+v"(hi2047));
-#pragma unroll 1
-    for (uint32_t base = 0; base < n_cols; base += 64u) {             // wave-uniform: once, twice for busy I pictures
-        const uint32_t k = base + (uint32_t)lane;
-        const bool act = k < n_cols;
-        uint32_t id = *reinterpret_cast<const uint8_t*>(lds + kOffSlots + k);        // k <= 127
-        id = act ? id : 0u;                               // idle lanes redo column 0 and write nothing
-        // id = half * 64 + c * 8 + b
-        char* const colp = lds + ((id & 0x47u) << 4) + ((id >> 2) & 14u);
-        int X[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) X[i] = *reinterpret_cast<const short*>(colp + i * 128);
-        const int bq = __builtin_amdgcn_ds_bpermute((int)((id & 7u) << 2), qia);      // lane b holds block b's macroblock
-        const bool bia = bq >= 256;
-        const uint32_t qv = (uint32_t)bq & 31u;
-        const char* const qt = lds + kOffQtab + (id & 56u);                          // column c of the tables
-        const v2u msel = *reinterpret_cast<const v2u*>(qt + (bia ? 0 : 64));
-        const v2u pm8 = *reinterpret_cast<const v2u*>(qt + 128);
-        int nim = bia ? 0 : -1;
-        asm("" : "+v"(nim));                              // keep it a mask (v_and), not a select
-        const bool dc_lane = bia && (id & 56u) == 0u;
-        uint64_t nz[8];
-#pragma unroll
-        for (int i = 0; i < 8; i++) nz[i] = lanes_nonzero(X[i]);
-        const int dc = X[0];
-        int rows_live = 1;                                // wave-uniform: 1 + highest row with a non-zero
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            // a row whose coefficients are zero in every column of the pass costs its compare and a scalar
-            // branch; in a live row every lane runs the branch-free form (zeros stay zero)
-            if (nz[i] != 0) {
-                rows_live = i + 1;
-                int P = (int)(((i < 4 ? pm8.x : pm8.y) >> (8 * (i & 3))) & 255u);
-                const int qO = (int)__umul24(qv, ((i < 4 ? msel.x : msel.y) >> (8 * (i & 3))) & 255u);   // quantiser_scale * Q[i][c] < 2^13
-                X[i] = dequant_any(X[i], qO, P, nim, lo2048, hi2047);
-            }
-        }
-        if (dc_lane) X[0] = dc * 256;                     // COL_4 / COL_INT_31
-        const ColOut co = butterfly8_col(X, rows_live);
-        // floor( float(v) * _y ): the int16 the reference hands from pass 1 to pass 2
-        const v2f k04 = {0.4f, 0.4f};
-        const v2f s07 = co.p07 * k04, s16 = co.p16 * k04, s52 = co.p52 * k04, s43 = co.p43 * k04;
-        // floor and conversion in one instruction (v_cvt_flr_i32_f32)
-        int wi[8] = {cvt_floor(s07.x), cvt_floor(s16.x), cvt_floor(s52.y), cvt_floor(s43.y),
-                     cvt_floor(s43.x), cvt_floor(s52.x), cvt_floor(s16.y), cvt_floor(s07.y)};
-        // |s| < 32768 for all eight: every floor(s) is an int16 as it stands
-        const float mx = fmaxf(fmaxf(fmaxf(fabsf(s07.x), fabsf(s16.x)), fmaxf(fabsf(s52.y), fabsf(s43.y))),
-                               fmaxf(fmaxf(fabsf(s43.x), fabsf(s52.x)), fmaxf(fabsf(s16.y), fabsf(s07.y))));
-        if (mx >= 32768.0f) {                             // outside any real stream: int16 wrap / saturation
-#pragma unroll
-            for (int n = 0; n < 8; n++) wi[n] = handoff16(wi[n]);
-        }
-        if (act) {
-#pragma unroll
-            for (int n = 0; n < 8; n++) *reinterpret_cast<short*>(colp + n * 128) = (short)wi[n];
-        }
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
 #pragma unroll
     for (int half = 0; half < 2; half++) {
@@ -936,7 +991,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
             // (exact products, the conversion truncates).  Columns that are dead in every block of the half give
             // zero inputs (wave-uniform): lane (c, b) of the liveness mask -> byte c
             const int cols_live = 8 - (__builtin_clzll(colbits | 1ull) >> 3);
-            const v4u wv = *reinterpret_cast<const v4u*>(lds + half * kLdsHalf + hi3 * 128 + lo3 * 16);
+            const v4u wv = *reinterpret_cast<const v4u*>(tile + half * kLdsHalf + hi3 * 128 + lo3 * 16);
             const v2f k25 = {2.5f, 2.5f};
             const v2f a = v2f{(float)(short)(wv.x & 0xffffu), (float)((int)wv.x >> 16)} * k25;
             const int Y0 = (int)a.x + 128, Y1 = (int)a.y;                           // "+128" of (t+128)/256
@@ -1009,19 +1064,75 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
                 *reinterpret_cast<v2u*>(dsp.apark + half * 512 + hi3 * 64 + lo3 * 8) = o;
             } else {
                 // converted right away (stage 5): the rows change lanes through the park
-                *reinterpret_cast<v2u*>(lds + kOffYpark + hi3 * 64 + lo3 * 8) = o;
+                if constexpr (Lay<LAYOUT>::park_in_tile) {      // the tile half is read out (stage 3): every lane's read has completed
+                    wait_lds_all();
+                    __builtin_amdgcn_wave_barrier();
+                }
+                *reinterpret_cast<v2u*>((Lay<LAYOUT>::park_in_tile ? tile + half * kLdsHalf : lds + kOffYpark) + hi3 * 64 + lo3 * 8) = o;
             }
         }
         if constexpr (DISPLAY && !CHROMA && AMODE != 1) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            display_half<AMODE>(pd, G, dsp, lds + kOffYpark, half, Rt, g, hi3, lo3);
+            display_half<AMODE>(pd, G, dsp, Lay<LAYOUT>::park_in_tile ? tile + half * kLdsHalf : lds + kOffYpark, half, Rt, g, hi3, lo3);
             // the next half parks its rows in the same place
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         }
+    }
+}
+
+// The two luma parts of a dense display task (P and B pictures) with ONE front: the coefficient rows of both parts are requested
+// together (two tiles), one liveness scan lists the live columns of all four halves, ONE column pass takes them -- a P or B part
+// has about a dozen live columns of 128, and a pass costs ~140 instructions however few of its 64 lanes have a column -- and then each
+// part runs its back half (maps from the chroma part, reference fetches, row passes, prediction, stores, conversion) as before.
+// I pictures keep a front per part: with ~40 live columns per part the shared pass would run twice anyway.
+template <int TYPE>
+__device__ __forceinline__ void recon_luma_pair(const PicDesc& pd, const Geom& G, int Rt, int gc, char* lds, int lane, Display dsp, MbCarry& carry, bool has_right)
+{
+    const int W = G.cw, hi3 = lane >> 3, lo3 = lane & 7;
+    char* const tileR = lds + kOffTileR;
+    // the previous part of this wave (the chroma part) may still be reading the tile
+    wait_lds_all();
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t row_off = (uint32_t)__mul24(16 * Rt + hi3, W);
+    {
+        const int Qld = 16 * gc + lo3;
+        const uint32_t voff = (2u * (row_off + (uint32_t)(8 * Qld))) | (Qld < (W >> 3) ? 0u : kOobBit);
+        coef_rows_to_lds(pd.coef[0], lds, voff, 0u);
+        coef_rows_to_lds(pd.coef[0], lds + kLdsHalf, voff, 16u * (uint32_t)W);
+    }
+    if (has_right) {
+        const int Qld = 16 * gc + 8 + lo3;
+        const uint32_t voff = (2u * (row_off + (uint32_t)(8 * Qld))) | (Qld < (W >> 3) ? 0u : kOobBit);
+        coef_rows_to_lds(pd.coef[0], tileR, voff, 0u);
+        coef_rows_to_lds(pd.coef[0], tileR + kLdsHalf, voff, 16u * (uint32_t)W);
+    }
+    // quantiser scale | intra << 8 of the macroblock of block b of either part, in lane b (the chroma part's lanes hold the task's
+    // eight macroblocks: lane m, macroblock m)
+    const int qiaL = __builtin_amdgcn_ds_bpermute((lo3 >> 1) << 2, (int)carry.flags) & 0x11f;
+    const int qiaR = __builtin_amdgcn_ds_bpermute((4 + (lo3 >> 1)) << 2, (int)carry.flags) & 0x11f;
+    wait_vmem_all();
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    uint64_t liveL[2], liveR[2] = {0, 0};
+    uint32_t n_cols = scan_tile(lds, lds + Lay<1>::slots, lane, 0u, 0u, liveL);
+    if (has_right) n_cols = scan_tile(tileR, lds + Lay<1>::slots, lane, 128u, n_cols, liveR);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    column_pass<true, false>(lds, (uint32_t)kOffTileR, lds + Lay<1>::slots, reinterpret_cast<const char*>(pd.qt), n_cols, qiaL, qiaR, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    dsp.side = 0;
+    recon_task<TYPE, false, false, true, 0, 2, true, 1>(pd, G, Rt, 2 * gc, lds, lane, dsp, carry, false, lds, liveL[0], liveL[1]);
+    if (has_right) {
+        dsp.side = 1;
+        recon_task<TYPE, false, false, true, 0, 2, true, 1>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp, carry, false, tileR, liveR[0], liveR[1]);
     }
 }
 
@@ -1117,7 +1228,7 @@ void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
     const int wg = xcd_remap(blockIdx.x, G.n_wg);
     int pic, twg;
     pic_of_wg<TYPE>(G, wg, pic, twg);
-    const int t = twg * kWavesPerWG + wave;
+    const int t = twg * (int)(blockDim.x >> 6) + wave;         // 4 waves per workgroup, 6 for the dense B kernel (launch_recon_type)
     // the conversion tables: 5 KB per workgroup, requested before anything else and needed only after the
     // chroma part -- the barrier below finds them long landed.  Every wave takes part, with or without a task.
     __shared__ __attribute__((aligned(16))) int32_t lut_s[kLdsLut / 4];      // static: its LDS address is a compile-time constant
@@ -1125,23 +1236,29 @@ void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
         const int32_t LEON_GLOBAL* src = gptr(T->rgba_lut);
         int32_t* dst = lut_s;
         int32_t v[5];
+        const uint32_t nt = blockDim.x;
 #pragma unroll
-        for (int k = 0; k < 5; k++) v[k] = src[threadIdx.x + 256 * k];
+        for (int k = 0; k < 5; k++) v[k] = threadIdx.x + nt * k < (uint32_t)(kLdsLut / 4) ? src[threadIdx.x + nt * k] : 0;
 #pragma unroll
-        for (int k = 0; k < 5; k++) dst[threadIdx.x + 256 * k] = v[k];
+        for (int k = 0; k < 5; k++) if (threadIdx.x + nt * k < (uint32_t)(kLdsLut / 4)) dst[threadIdx.x + nt * k] = v[k];
     }
     const bool live = t < G.tasks_per_pic && pic < G.n_pics;
-    char* lds = smem + wave * (ALPHA ? kLdsPerWaveDisplayAlpha : kLdsPerWaveDisplay);
+    constexpr bool kPair = LEON_PAIR_LUMA && LEON_CARRY && !SPARSE && !ALPHA && TYPE != 1;      // recon_luma_pair
+    char* lds = smem + wave * (ALPHA ? kLdsPerWaveDisplayAlpha : (kPair ? kLdsPerWaveDisplayPair : kLdsPerWaveDisplay));
     const PicDesc& pd = descs[live ? pic : 0];
     const int Rt = div_inv(t, G.inv_gC), gc = t - Rt * G.gC;
-    Display dsp{lds + kOffStash, 0, lds + kLdsPerWaveDisplay, reinterpret_cast<const char*>(lut_s)};
-    stage_tables(pd.qt, lds, lane);
+    Display dsp{lds + (kPair ? Lay<1>::stash : Lay<0>::stash), 0, lds + kLdsPerWaveDisplay, reinterpret_cast<const char*>(lut_s)};
+    if constexpr (!kPair) stage_tables(pd.qt, lds, lane);
     MbCarry carry{};
-    if (live) recon_task<TYPE, true, SPARSE, true, 0, LEON_CARRY ? 1 : 0>(pd, G, Rt, gc, lds, lane, dsp, carry);
+    if (live) recon_task<TYPE, true, SPARSE, true, 0, LEON_CARRY ? 1 : 0, false, kPair ? 1 : 0>(pd, G, Rt, gc, lds, lane, dsp, carry);
     __syncthreads();
     if (!live) return;
     // the two luma parts as two calls, not a loop: the loop form keeps 15 more registers live (B path: 93).
     // yuva: the A part of the same four macroblocks first (AMODE 1), then the Y part that displays them (AMODE 2).
+    if constexpr (kPair) {
+        recon_luma_pair<TYPE>(pd, G, Rt, gc, lds, lane, dsp, carry, 2 * gc + 1 < G.gY);
+        return;
+    }
     dsp.side = 0;
     if constexpr (ALPHA) {
         recon_task<TYPE, false, SPARSE, true, 1, LEON_CARRY ? 2 : 0>(pd, G, Rt, 2 * gc, lds, lane, dsp, carry, true);
