@@ -5,7 +5,9 @@
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=${1:-gpurun_out/prof}
 mkdir -p $out
-B="python3 bench.py --no-cpu-baseline --no-second-recipe"
+# (--no-placement: the start-up step that draws every region twice launches the same kernels on the draws it rejects; the trace
+#  and the counters are to show the launches of the steps)
+B="python3 bench.py --no-cpu-baseline --no-second-recipe --no-end-to-end --no-placement"
 S="$B --steps 2 --warmup 1"
 echo "== trace";  timeout -k 10 300 rocprofv3 --kernel-trace --stats -d $out/kt --output-format csv -- $B > $out/kt.log 2>&1 || echo "trace failed"
 echo "== fetch";  timeout -k 10 400 rocprofv3 --pmc FETCH_SIZE -d $out/pf --output-format csv -- $S > $out/pf.log 2>&1 || echo "fetch failed"
