@@ -5,6 +5,7 @@
 #include "leon_vlc_gpu.h"
 
 #include <atomic>
+#include <sys/stat.h>
 #include <chrono>
 #include <condition_variable>
 #include <deque>
@@ -656,7 +657,8 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
     const std::string cdir = capture ? p->capture_dir + "/w" + std::to_string(w->id) : std::string();
     FILE* cidx = nullptr;
     if (capture) {
-        (void)!system(("mkdir -p '" + cdir + "'").c_str());
+        (void)mkdir(p->capture_dir.c_str(), 0777);          // (both may exist)
+        (void)mkdir(cdir.c_str(), 0777);
         cidx = fopen((cdir + "/index.txt").c_str(), "w");
         if (cidx) fprintf(cidx, "geom coded=%dx%d frame=%dx%d mbs=%d n_groups=%d gpu_parser=%d unfused=%d slot_bytes=%zu\n", p->vinfo.coded_width, p->vinfo.coded_height,
                           p->vinfo.frame_width, p->vinfo.frame_height, p->vinfo.mb_width * p->vinfo.mb_height, p->vinfo.n_groups, (int)p->gpu_parser, (int)p->unfused, d->plane_bytes);
