@@ -140,6 +140,9 @@ static constexpr int kOffTileR = Lay<1>::tile_r;
 #ifndef LEON_PAIR_LUMA
 #define LEON_PAIR_LUMA 1
 #endif
+#ifndef LEON_NINTH_FROM_BELOW
+#define LEON_NINTH_FROM_BELOW 1
+#endif
 
 // ---- small helpers -----------------------------------------------------------
 
@@ -519,12 +522,23 @@ __device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, in
 
 // second half of fetch_rows: the lower row comes from the lane 8 above (same block, next sample
 // row) -- or from the lane itself when the vector has no vertical half-pel part
-__device__ __forceinline__ void finish_rows(RefRows& R, int ov, bool last_row, int lane)
+// `below` (luma, upper half): the half underneath belongs to the same macroblocks, its first row IS the ninth row of this one -- same
+// vector, same clamped row address (fetch_rows: r1 of row y equals r0 of row y + 1 at every edge) -- so the upper half fetches no ninth
+// row of its own: its last lanes take it from the lower half's first lanes ((lane + 8) & 63 is that lane).
+__device__ __forceinline__ void finish_rows(RefRows& R, int ov, bool last_row, int lane, const RefRows* below = nullptr)
 {
     const int src = (ov ? ((lane + 8) & 63) : lane) << 2;
     const uint32_t n0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)R.l0);
     const uint32_t n1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)R.l1);
     const uint32_t n2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)R.l2);
+    if (below) {
+        const uint32_t b0 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)below->l0);
+        const uint32_t b1 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)below->l1);
+        const uint32_t b2 = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)below->l2);
+        const bool wrap = last_row && ov;
+        R.m0 = wrap ? b0 : n0; R.m1 = wrap ? b1 : n1; R.m2 = wrap ? b2 : n2;
+        return;
+    }
     if (!(last_row && ov)) { R.m0 = n0; R.m1 = n1; R.m2 = n2; }
 }
 
@@ -925,8 +939,10 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
         for (int h = 0; h < 2; h++) {
             const int Rh = CHROMA ? Rt : 2 * Rt + h;
             const uint32_t po = CHROMA ? (h == 0 ? ysz : ysz + (ysz >> 2)) : a_off;
-            if (any_f) rfh[h] = fetch_rows(gptr(pd.ref_fwd) + po, W, H, 8 * Rh + hi3, pxA, ayA, ohA, ovA, inA, hi3 == 7, useA);
-            if (TYPE == 3 && any_b) rbh[h] = fetch_rows(gptr(pd.ref_bwd) + po, W, H, 8 * Rh + hi3, pxB, ayB, ohB, ovB, inB, hi3 == 7, useB);
+            // (luma, upper half: no ninth row of its own -- finish_rows takes it from the lower half)
+            const bool ninth = hi3 == 7 && (CHROMA || h == 1 || !LEON_NINTH_FROM_BELOW);
+            if (any_f) rfh[h] = fetch_rows(gptr(pd.ref_fwd) + po, W, H, 8 * Rh + hi3, pxA, ayA, ohA, ovA, inA, ninth, useA);
+            if (TYPE == 3 && any_b) rbh[h] = fetch_rows(gptr(pd.ref_bwd) + po, W, H, 8 * Rh + hi3, pxB, ayB, ohB, ovB, inB, ninth, useB);
         }
     }
 
@@ -1021,13 +1037,13 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
         if (TYPE != 1) {
             v2u pred = {0u, 0u};
             if (any_f) {
-                finish_rows(rf, ovA, hi3 == 7, lane);
+                finish_rows(rf, ovA, hi3 == 7, lane, !CHROMA && half == 0 && LEON_NINTH_FROM_BELOW ? &rfh[1] : nullptr);
                 pred = predict8(rf);
             }
             if (TYPE == 3) {
                 v2u pb = {0u, 0u};
                 if (any_b) {
-                    finish_rows(rb, ovB, hi3 == 7, lane);
+                    finish_rows(rb, ovB, hi3 == 7, lane, !CHROMA && half == 0 && LEON_NINTH_FROM_BELOW ? &rbh[1] : nullptr);
                     pb = predict8(rb);
                 }
                 v2u pf = usef ? pred : pb;
