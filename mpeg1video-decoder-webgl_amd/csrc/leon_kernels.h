@@ -143,6 +143,9 @@ static constexpr int kOffTileR = Lay<1>::tile_r;
 #ifndef LEON_NINTH_FROM_BELOW
 #define LEON_NINTH_FROM_BELOW 1
 #endif
+#ifndef LEON_NO_PLANES_BRANCH
+#define LEON_NO_PLANES_BRANCH 1
+#endif
 
 // ---- small helpers -----------------------------------------------------------
 
@@ -1068,10 +1071,16 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
         if constexpr (!DISPLAY) {
             __builtin_amdgcn_raw_buffer_store_b64(o, buf_rsrc(pd.out + plane_off), (int)out_voff, (int)(half ? half_step : 0u), 0);
         } else {
-            // planes only for pictures that will be predicted from (wave-uniform: a resource without records drops the store)
+            // planes only for pictures that will be predicted from.  A scalar branch (the flag is the picture's): until round 4 the
+            // store was issued into a resource without records, which drops it -- after the texture path has processed it; a B task
+            // issued six such stores among its 54 memory instructions
+#if LEON_NO_PLANES_BRANCH
+            if (!pd.no_planes) __builtin_amdgcn_raw_buffer_store_b64(o, buf_rsrc(pd.out + plane_off), (int)out_voff, (int)(half ? half_step : 0u), 0);
+#else
             const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
                 (void*)(pd.out + plane_off), 0, pd.no_planes ? 0 : 0x7fffffff, 0x00020000);
             __builtin_amdgcn_raw_buffer_store_b64(o, prs, (int)out_voff, (int)(half ? half_step : 0u), 0);
+#endif
             if constexpr (CHROMA) {
                 // park the samples for the luma parts: [plane = half][row hi3][8 bytes of macroblock lo3]
                 *reinterpret_cast<v2u*>(dsp.stash + half * 512 + hi3 * 64 + lo3 * 8) = o;
