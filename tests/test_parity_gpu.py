@@ -421,3 +421,60 @@ def test_descriptor_ring_wraps_without_draining_the_stream(L, O, S):
         assert np.array_equal(planes_flat(*dec.read_planes(500)), exp)
     finally:
         dec.close()
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["k_recon", "k_recon_display"])
+def test_pictures_of_one_batch_with_different_matrix_sets(L, O, S, fused):
+    """leon_add_quant_matrices + leon_picture.qm_set (ABI 3): the reference reloads both matrices at every sequence header
+    (decoders/jsv.js:540-558); a batch may hold pictures of different sequences -- each is dequantised with ITS set, in one
+    launch.  Three I pictures and three P pictures, sets 0 (leon_set_quant_matrices), 1 and 2, against the oracle with the
+    matrices of each; the same matrices registered twice give the same id; an unknown set is refused."""
+    import torch
+    cw, ch = 96, 64
+    rng = np.random.default_rng(21)
+    mats = [np.concatenate([rng.integers(1, 60, size=64), rng.integers(1, 60, size=64)]).astype(np.uint8) for _ in range(3)]
+    for m in mats:
+        m[0] = 8
+    dec = L.Decoder(cw, ch, n_slots=12)
+    try:
+        dec.set_quant_matrices(mats[0][:64], mats[0][64:])
+        ids = [0, dec.add_quant_matrices(mats[1][:64], mats[1][64:]), dec.add_quant_matrices(mats[2][:64], mats[2][64:])]
+        assert ids == [0, 1, 2] and dec.add_quant_matrices(mats[1][:64], mats[1][64:]) == 1
+        tens_i = [S.make_picture(rng, cw, ch, S.PIC_I) for _ in range(3)]
+        tens_p = [S.make_picture(rng, cw, ch, S.PIC_P) for _ in range(3)]
+        frames = torch.zeros((6, ch, cw, 4), dtype=torch.uint8, device="cuda") if fused else None
+        keep = []
+
+        def batch(tens, first_slot, refs, f0):
+            pics = []
+            for i, t in enumerate(tens):
+                d = {k: torch.from_numpy(np.ascontiguousarray(v)).cuda() for k, v in t.items() if isinstance(v, np.ndarray)}
+                keep.append(d)
+                ptr = lambda k, d=d: d[k].data_ptr() if k in d else None
+                pics.append(L.make_picture(t["type"], first_slot + i, ptr("coef_y"), ptr("coef_cb"), ptr("coef_cr"), ptr("qscale"), ptr("intra"),
+                                           ptr("repadd"), ptr("mv_fwd"), None, None, ref_fwd_slot=-1 if refs is None else refs + i, device=True,
+                                           qm_set=ids[i], rgba_out=frames[f0 + i].data_ptr() if fused else None))
+            torch.cuda.synchronize()
+            dec.submit_batch(pics, L.MEM_DEVICE)
+        batch(tens_i, 0, None, 0)
+        batch(tens_p, 3, 0, 3)
+        dec.sync()
+        for i in range(3):
+            exp_i = O.decode_picture(S.PIC_I, cw, ch, tens_i[i]["coef_y"], tens_i[i]["coef_cb"], tens_i[i]["coef_cr"], tens_i[i]["qscale"], tens_i[i]["intra"], qm=mats[i])
+            assert np.array_equal(planes_flat(*dec.read_planes(i)), exp_i), "I picture with matrix set %d" % ids[i]
+            t = tens_p[i]
+            exp_p = O.decode_picture(S.PIC_P, cw, ch, t["coef_y"], t["coef_cb"], t["coef_cr"], t["qscale"], t["intra"], repadd=t["repadd"],
+                                     mv_fwd=t["mv_fwd"], qm=mats[i], ref_fwd=exp_i)
+            assert np.array_equal(planes_flat(*dec.read_planes(3 + i)), exp_p), "P picture with matrix set %d" % ids[i]
+            if fused:
+                y, cb, cr = O.split_planes(exp_p, cw, ch)
+                assert np.array_equal(frames[3 + i].cpu().numpy(), O.ycbcr_to_rgba(y, cb, cr, cw, cw, ch, "cpu"))
+        # the sets really differ in their effect
+        other = O.decode_picture(S.PIC_I, cw, ch, tens_i[1]["coef_y"], tens_i[1]["coef_cb"], tens_i[1]["coef_cr"], tens_i[1]["qscale"], tens_i[1]["intra"], qm=mats[0])
+        assert not np.array_equal(other, planes_flat(*dec.read_planes(1)))
+        bad = L.make_picture(S.PIC_I, 9, keep[0]["coef_y"].data_ptr(), keep[0]["coef_cb"].data_ptr(), keep[0]["coef_cr"].data_ptr(),
+                             keep[0]["qscale"].data_ptr(), keep[0]["intra"].data_ptr(), device=True, qm_set=7)
+        with pytest.raises(L.LeonError):
+            dec.submit_batch([bad], L.MEM_DEVICE)
+    finally:
+        dec.close()
