@@ -35,5 +35,6 @@ def run(n, threads):
 for rep in range(2):
     pics, secs, rates = run(1, 16)
     print("1 pipeline   %7.0f pictures/s  (%d pictures in %.2f s)" % (pics / secs, pics, secs), flush=True)
-    pics, secs, rates = run(2, 8)
-    print("2 pipelines  %7.0f pictures/s  (%d pictures, slower one %.2f s; each %s)" % (pics / secs, pics, secs, rates), flush=True)
+    for n in (2, 3, 4):
+        pics, secs, rates = run(n, max(2, 16 // n))
+        print("%d pipelines  %7.0f pictures/s  (%d pictures, slowest %.2f s; each %s)" % (n, pics / secs, pics, secs, rates), flush=True)
