@@ -143,6 +143,9 @@ static constexpr int kOffTileR = Lay<1>::tile_r;
 #ifndef LEON_NINTH_FROM_BELOW
 #define LEON_NINTH_FROM_BELOW 1
 #endif
+#ifndef LEON_ABL
+#define LEON_ABL 0      // ablation builds (tools/ab_build.sh x -DLEON_ABL=n): 1 no reference loads, 2 no RGBA stores, 4 no display conversion at all; WRONG output, timing only
+#endif
 #ifndef LEON_NO_PLANES_BRANCH
 #define LEON_NO_PLANES_BRANCH 1
 #endif
@@ -511,8 +514,8 @@ __device__ __forceinline__ RefRows fetch_rows(const LEON_GLOBAL uint8_t* ref, in
         uint32_t xo = (uint32_t)px & ~3u;
         // buffer loads: wave-uniform descriptor in SGPRs + 32-bit offset, no 64-bit address math
         const __amdgpu_buffer_rsrc_t rs = buf_rsrc((const void*)ref);
-        const v3u a = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(use ? r0 + xo : kOobBit), 0, 0);
-        const v3u c = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(use && last_row && ov ? r1 + xo : kOobBit), 0, 0);
+        const v3u a = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(use && !(LEON_ABL & 1) ? r0 + xo : kOobBit), 0, 0);
+        const v3u c = __builtin_amdgcn_raw_buffer_load_b96(rs, (int)(use && last_row && ov && !(LEON_ABL & 1) ? r1 + xo : kOobBit), 0, 0);
         R.l0 = a.x; R.l1 = a.y; R.l2 = a.z;
         R.m0 = c.x; R.m1 = c.y; R.m2 = c.z;
     } else {                                         // vector leaves the picture (rare)
@@ -686,9 +689,10 @@ __device__ __forceinline__ void display_half(const PicDesc& pd, const Geom& G, c
     const uint32_t row_off = __umul24((uint32_t)yrow, (uint32_t)G.fw) + (uint32_t)xa;     // both < 4096
     const bool in_a = yrow < G.fh && xa < G.fw, in_b = yrow + 1 < G.fh && xa < G.fw;
     const v4u pa = rgba_row4<AMODE == 2>(dsp.lut, ya, c0, c1, aa, two, k21);
-    __builtin_amdgcn_raw_buffer_store_b128(pa, rrs, (int)((row_off * 4u) | (in_a ? 0u : kOobBit)), 0, 0);
+    if (!(LEON_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(pa, rrs, (int)((row_off * 4u) | (in_a ? 0u : kOobBit)), 0, 0);
     const v4u pb = rgba_row4<AMODE == 2>(dsp.lut, yb, c0, c1, ab, two, k21);
-    __builtin_amdgcn_raw_buffer_store_b128(pb, rrs, (int)(((row_off + (uint32_t)G.fw) * 4u) | (in_b ? 0u : kOobBit)), 0, 0);
+    if (!(LEON_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(pb, rrs, (int)(((row_off + (uint32_t)G.fw) * 4u) | (in_b ? 0u : kOobBit)), 0, 0);
+    if (LEON_ABL & 2) asm volatile("" :: "v"(pa.x ^ pa.y ^ pa.z ^ pa.w ^ pb.x ^ pb.y ^ pb.z ^ pb.w));      // keep the conversion alive
 }
 
 // ---- stage 2 as functions: the liveness scan of a tile and the column pass over a list of live columns ------------------------
@@ -1100,7 +1104,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            display_half<AMODE>(pd, G, dsp, Lay<LAYOUT>::park_in_tile ? tile + half * kLdsHalf : lds + kOffYpark, half, Rt, g, hi3, lo3);
+            if (!(LEON_ABL & 4)) display_half<AMODE>(pd, G, dsp, Lay<LAYOUT>::park_in_tile ? tile + half * kLdsHalf : lds + kOffYpark, half, Rt, g, hi3, lo3);
             // the next half parks its rows in the same place
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
