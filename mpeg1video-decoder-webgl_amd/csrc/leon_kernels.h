@@ -143,6 +143,12 @@ static constexpr int kOffTileR = Lay<1>::tile_r;
 #ifndef LEON_NINTH_FROM_BELOW
 #define LEON_NINTH_FROM_BELOW 1
 #endif
+#ifndef LEON_RGBA_AUX
+#define LEON_RGBA_AUX 2    // cache policy bits of the frames' stores (1 sc0, 2 nt, 16 sc1).  nt: the GPU never reads a frame again, and written
+                          // through the caches like everything else it pushes the reference planes out -- round 4, one box, alternating: 5.944 ->
+                          // 5.818 ms per step (I -5 %, P -3.6 %, mixed B -1.2 %); sc0 / sc1: nothing.  (Round 2 measured nt on ALL stores: -4 %,
+                          // the planes are read again.)
+#endif
 #ifndef LEON_ABL
 #define LEON_ABL 0      // ablation builds (tools/ab_build.sh x -DLEON_ABL=n): 1 no reference loads, 2 no RGBA stores, 4 no display conversion at all; WRONG output, timing only
 #endif
@@ -689,9 +695,9 @@ __device__ __forceinline__ void display_half(const PicDesc& pd, const Geom& G, c
     const uint32_t row_off = __umul24((uint32_t)yrow, (uint32_t)G.fw) + (uint32_t)xa;     // both < 4096
     const bool in_a = yrow < G.fh && xa < G.fw, in_b = yrow + 1 < G.fh && xa < G.fw;
     const v4u pa = rgba_row4<AMODE == 2>(dsp.lut, ya, c0, c1, aa, two, k21);
-    if (!(LEON_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(pa, rrs, (int)((row_off * 4u) | (in_a ? 0u : kOobBit)), 0, 0);
+    if (!(LEON_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(pa, rrs, (int)((row_off * 4u) | (in_a ? 0u : kOobBit)), 0, LEON_RGBA_AUX);
     const v4u pb = rgba_row4<AMODE == 2>(dsp.lut, yb, c0, c1, ab, two, k21);
-    if (!(LEON_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(pb, rrs, (int)(((row_off + (uint32_t)G.fw) * 4u) | (in_b ? 0u : kOobBit)), 0, 0);
+    if (!(LEON_ABL & 2)) __builtin_amdgcn_raw_buffer_store_b128(pb, rrs, (int)(((row_off + (uint32_t)G.fw) * 4u) | (in_b ? 0u : kOobBit)), 0, LEON_RGBA_AUX);
     if (LEON_ABL & 2) asm volatile("" :: "v"(pa.x ^ pa.y ^ pa.z ^ pa.w ^ pb.x ^ pb.y ^ pb.z ^ pb.w));      // keep the conversion alive
 }
 
