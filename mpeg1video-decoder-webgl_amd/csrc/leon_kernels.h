@@ -1252,47 +1252,29 @@ __global__ __launch_bounds__(kReconMaxThreads) void k_recon(const PicDesc* __res
 // for that), the chroma part first, then the left and the right luma part.
 // The sparse B kernel (what the pipeline runs most) is held to 72 registers = 7 waves per SIMD: it wants 74, the two
 // spilled dwords (8 bytes of scratch per lane) cost less than the wave brings: +1..2 % end to end, three pairs on one box.
-template <int TYPE, bool SPARSE, bool ALPHA = false>
-__global__ __launch_bounds__(kReconMaxThreads) __attribute__((amdgpu_waves_per_eu(TYPE == 3 && !ALPHA && (SPARSE || LEON_CARRY) ? 7 : 4)))
-void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
-                                                                    const Tables* __restrict__ T)
+// one display task of a wave: the chroma part, the workgroup's barrier in front of the first table lookup (`first`: every wave of the
+// workgroup comes by here exactly once), the luma parts.  false: the wave has no task (and none behind this one).
+template <int TYPE, bool SPARSE, bool ALPHA>
+__device__ __forceinline__ bool display_task(const PicDesc* __restrict__ descs, const Geom& G, int pic, int t, char* lds, int lane, const char* lut, bool first)
 {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int lane = threadIdx.x & 63;
-    const int wg = xcd_remap(blockIdx.x, G.n_wg);
-    int pic, twg;
-    pic_of_wg<TYPE>(G, wg, pic, twg);
-    const int t = twg * (int)(blockDim.x >> 6) + wave;         // 4 waves per workgroup, 6 for the dense B kernel (launch_recon_type)
-    // the conversion tables: 5 KB per workgroup, requested before anything else and needed only after the
-    // chroma part -- the barrier below finds them long landed.  Every wave takes part, with or without a task.
-    __shared__ __attribute__((aligned(16))) int32_t lut_s[kLdsLut / 4];      // static: its LDS address is a compile-time constant
-    {
-        const int32_t LEON_GLOBAL* src = gptr(T->rgba_lut);
-        int32_t* dst = lut_s;
-        int32_t v[5];
-        const uint32_t nt = blockDim.x;
-#pragma unroll
-        for (int k = 0; k < 5; k++) v[k] = threadIdx.x + nt * k < (uint32_t)(kLdsLut / 4) ? src[threadIdx.x + nt * k] : 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++) if (threadIdx.x + nt * k < (uint32_t)(kLdsLut / 4)) dst[threadIdx.x + nt * k] = v[k];
-    }
-    const bool live = t < G.tasks_per_pic && pic < G.n_pics;
     constexpr bool kPair = LEON_PAIR_LUMA && LEON_CARRY && !SPARSE && !ALPHA && TYPE != 1;      // recon_luma_pair
-    char* lds = smem + wave * (ALPHA ? kLdsPerWaveDisplayAlpha : (kPair ? kLdsPerWaveDisplayPair : kLdsPerWaveDisplay));
+    const bool live = t < G.tasks_per_pic && pic < G.n_pics;
     const PicDesc& pd = descs[live ? pic : 0];
     const int Rt = div_inv(t, G.inv_gC), gc = t - Rt * G.gC;
-    Display dsp{lds + (kPair ? Lay<1>::stash : Lay<0>::stash), 0, lds + kLdsPerWaveDisplay, reinterpret_cast<const char*>(lut_s)};
-    if constexpr (!kPair) stage_tables(pd.qt, lds, lane);
+    Display dsp{lds + (kPair ? Lay<1>::stash : Lay<0>::stash), 0, lds + kLdsPerWaveDisplay, lut};
+    if constexpr (!kPair) {
+        if (!first) { wait_lds_all(); __builtin_amdgcn_wave_barrier(); }      // the column pass of the task before has read its tables
+        stage_tables(pd.qt, lds, lane);
+    }
     MbCarry carry{};
     if (live) recon_task<TYPE, true, SPARSE, true, 0, LEON_CARRY ? 1 : 0, false, kPair ? 1 : 0>(pd, G, Rt, gc, lds, lane, dsp, carry);
-    __syncthreads();
-    if (!live) return;
+    if (first) __syncthreads();          // the conversion tables have landed
+    if (!live) return false;
     // the two luma parts as two calls, not a loop: the loop form keeps 15 more registers live (B path: 93).
     // yuva: the A part of the same four macroblocks first (AMODE 1), then the Y part that displays them (AMODE 2).
     if constexpr (kPair) {
         recon_luma_pair<TYPE>(pd, G, Rt, gc, lds, lane, dsp, carry, 2 * gc + 1 < G.gY);
-        return;
+        return true;
     }
     dsp.side = 0;
     if constexpr (ALPHA) {
@@ -1310,6 +1292,40 @@ void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
             recon_task<TYPE, false, SPARSE, true, 0, LEON_CARRY ? 2 : 0>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp, carry);
         }
     }
+    return true;
+}
+
+template <int TYPE, bool SPARSE, bool ALPHA = false>
+__global__ __launch_bounds__(kReconMaxThreads) __attribute__((amdgpu_waves_per_eu(TYPE == 3 && !ALPHA && (SPARSE || LEON_CARRY) ? 7 : 4)))
+void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
+                                                                    const Tables* __restrict__ T)
+{
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int lane0 = threadIdx.x & 63;
+    const int wg = xcd_remap(blockIdx.x, G.n_wg);
+    int pic, twg;
+    pic_of_wg<TYPE>(G, wg, pic, twg);
+    const int wpw = (int)(blockDim.x >> 6);
+    // the conversion tables: 5 KB per workgroup, requested before anything else and needed only after the
+    // chroma part -- the barrier in display_task finds them long landed.  Every wave takes part, with or without a task.
+    __shared__ __attribute__((aligned(16))) int32_t lut_s[kLdsLut / 4];      // static: its LDS address is a compile-time constant
+    {
+        const int32_t LEON_GLOBAL* src = gptr(T->rgba_lut);
+        int32_t* dst = lut_s;
+        int32_t v[5];
+        const uint32_t nt = blockDim.x;
+#pragma unroll
+        for (int k = 0; k < 5; k++) v[k] = threadIdx.x + nt * k < (uint32_t)(kLdsLut / 4) ? src[threadIdx.x + nt * k] : 0;
+#pragma unroll
+        for (int k = 0; k < 5; k++) if (threadIdx.x + nt * k < (uint32_t)(kLdsLut / 4)) dst[threadIdx.x + nt * k] = v[k];
+    }
+    constexpr bool kPair = LEON_PAIR_LUMA && LEON_CARRY && !SPARSE && !ALPHA && TYPE != 1;
+    char* lds = smem + wave * (ALPHA ? kLdsPerWaveDisplayAlpha : (kPair ? kLdsPerWaveDisplayPair : kLdsPerWaveDisplay));
+    // (Round 4 tried a wave running two to five tasks one after the other, so that the frames' stores of a task drain while the wave
+    // works on the next: 5.89-5.92 ms per step with two against 5.90-5.95 with one, worse with three and five, and 10-20 registers more
+    // for the loop -- not kept.)
+    display_task<TYPE, SPARSE, ALPHA>(descs, G, pic, twg * wpw + wave, lds, lane0, reinterpret_cast<const char*>(lut_s), true);
 }
 
 // ---- K3: YCbCr 4:2:0 -> RGBA8 ------------------------------------------------------
