@@ -63,7 +63,14 @@ typedef struct leon_pipeline_config {
      *   LEON_PIPELINE_PARSER_HOST (-1): on the parser threads (libleon_vlc.so).
      * Same frames either way. */
     int32_t gpu_parser;
-    int32_t reserved;
+    /* Arithmetic of the frames' colour conversion, leon.h's LEON_RGB_*:
+     *   LEON_RGB_CPU_TWIN (0): the integer-exact twin of the reference's CPU conversion, fused into the reconstruction launches
+     *     (what every other path of this library delivers; bit-exact to the oracle).
+     *   LEON_RGB_GL (1): the fp32 arithmetic of the reference's LIVE display -- renderFrameGL drawing with
+     *     SHADER_FRAGMENT_YCBCRTORGBA (player/easybits.player.js:2787-2858, player/parts/end.js:77-156) -- for a host that
+     *     wants the pixels the page shows (within 1 LSB of the executed reference's canvas, tests/test_pipeline_gl_flavour_gpu.py).
+     *     Takes the unfused road: every picture writes its planes, one k_rgba_gl launch per picture.  Not with yuva streams. */
+    int32_t display_flavour;
 } leon_pipeline_config;
 
 /* One decoded picture.  rgba stays valid until leon_pipeline_release_window(window) */
@@ -93,7 +100,7 @@ typedef struct leon_pipeline_info {
     uint32_t first_gop;         /* key-map entry the run starts with (start_seconds) */
     int32_t parser_threads, gops_per_window;
     int32_t gpu_parser;         /* 1: the slice layer is decoded on the GPU, 0: on the parser threads (what LEON_PIPELINE_PARSER_DEFAULT chose) */
-    int32_t reserved;
+    int32_t display_flavour;    /* LEON_RGB_CPU_TWIN / LEON_RGB_GL, as configured */
 } leon_pipeline_info;
 
 typedef struct leon_pipeline_stats {

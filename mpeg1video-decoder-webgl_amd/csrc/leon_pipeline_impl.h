@@ -91,7 +91,8 @@ struct leon_pipeline {
     std::vector<double> st_window_done;                      // LEON_DEBUG_PIPE_TIMING: when each window completed (seconds from the start)
     uint64_t st_wait_ring_ns = 0, st_wait_scan_ns = 0;       // submit thread: waiting for a ring entry / for the window's GOPs to be parsed
     std::string capture_dir;     // LEON_DEBUG_CAPTURE=<dir> at create: everything a window's launches read and wrote goes to files (capture_*)
-    bool unfused = false;        // frame_width % 8 != 0: planes for every picture, one display conversion launch per picture
+    bool unfused = false;        // frame_width % 8 != 0, or the GL flavour: planes for every picture, one display conversion launch per picture
+    int flavour = LEON_RGB_CPU_TWIN;      // leon_pipeline_config.display_flavour
     size_t frame_bytes = 0;
 
     leon_decoder* dec = nullptr;
@@ -695,7 +696,7 @@ int submit_window(leon_pipeline* p, PipeWindow* w)
         if (rc != LEON_OK) return rc;
         if (p->unfused)
             for (const Item& it : lvl) {
-                rc = leon_convert_rgba(d, it.out, ring + ((size_t)it.lane * p->max_pics + (size_t)it.pic->tref) * p->frame_bytes, LEON_MEM_DEVICE, LEON_RGB_CPU_TWIN);
+                rc = leon_convert_rgba(d, it.out, ring + ((size_t)it.lane * p->max_pics + (size_t)it.pic->tref) * p->frame_bytes, LEON_MEM_DEVICE, p->flavour);
                 if (rc != LEON_OK) return rc;
             }
         if (capture) {
@@ -1018,8 +1019,15 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
     // the fused display conversion writes eight pixels per lane: it needs frame_width % 8 == 0.  The reference crops to
     // any width (player/easybits.player.js:2818): such a stream takes the slow road -- every picture (B pictures too)
     // writes its planes, and one leon_convert_rgba per picture (the generic k_rgba_twin) fills the window's frames.
-    p->unfused = (p->vinfo.frame_width & 7) != 0;
-    if (p->unfused && p->vinfo.has_alpha == 1) { delete p; return fail(LEON_ERR_INVALID, "a yuva stream needs frame_width %% 8 == 0 in the pipeline (it is %d)", p->vinfo.frame_width); }
+    // The GL flavour (the reference's live display arithmetic, fp32) exists as a launch of its own only: the same road.
+    if (cfg->display_flavour != LEON_RGB_CPU_TWIN && cfg->display_flavour != LEON_RGB_GL) { delete p; return fail(LEON_ERR_INVALID, "display_flavour %d", cfg->display_flavour); }
+    p->flavour = cfg->display_flavour;
+    p->info.display_flavour = p->flavour;
+    p->unfused = (p->vinfo.frame_width & 7) != 0 || p->flavour == LEON_RGB_GL;
+    if (p->unfused && p->vinfo.has_alpha == 1) {
+        delete p;
+        return fail(LEON_ERR_INVALID, "a yuva stream needs frame_width %% 8 == 0 (it is %d) and the CPU-twin display flavour in the pipeline", p->vinfo.frame_width);
+    }
 
     leon_config dc{};
     dc.coded_width = p->vinfo.coded_width; dc.coded_height = p->vinfo.coded_height;

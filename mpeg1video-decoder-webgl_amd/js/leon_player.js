@@ -121,7 +121,8 @@ class LeonPlayer extends EventEmitter {
     this._stopPipeline();
     const p = this._pipe = new LeonPipeline(Buffer.from(this._bytes.buffer, this._bytes.byteOffset, this._bytes.byteLength),
       { backend: this.opts.backend, parserThreads: this.opts.parserThreads, gopsPerWindow: 1, windowsInFlight: 2, autoRelease: false, startSeconds,
-        gpuParser: this.opts.gpuParser === undefined ? 0 : (this.opts.gpuParser ? 1 : -1) });      // opts.gpuParser: the slice layer on the GPU (include/leon_pipeline.h)
+        gpuParser: this.opts.gpuParser === undefined ? 0 : (this.opts.gpuParser ? 1 : -1),       // opts.gpuParser: the slice layer on the GPU (include/leon_pipeline.h)
+        displayFlavour: this.opts.displayFlavour | 0 });      // 1: the fp32 arithmetic of the page's renderFrameGL (player/parts/end.js:77-156)
     const s = p.stats();
     this.videoWidth = s.frameWidth; this.videoHeight = s.frameHeight; this.frameDuration = 1000 / (s.pictureRate || 25);
     if (s.duration) this.duration = s.duration;

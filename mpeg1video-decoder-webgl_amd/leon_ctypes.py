@@ -87,7 +87,7 @@ class PipelineConfig(C.Structure):
     _fields_ = [("device_id", C.c_int32), ("parser_threads", C.c_int32), ("gops_per_window", C.c_int32),
                 ("windows_in_flight", C.c_int32), ("max_gop_pictures", C.c_int32), ("loop", C.c_int32),
                 ("shard_index", C.c_int32), ("shard_count", C.c_int32), ("start_seconds", C.c_double),
-                ("gpu_parser", C.c_int32), ("reserved", C.c_int32)]
+                ("gpu_parser", C.c_int32), ("display_flavour", C.c_int32)]
 
 
 class PipelineFrame(C.Structure):
@@ -99,7 +99,7 @@ class PipelineInfo(C.Structure):
     _fields_ = [("coded_width", C.c_int32), ("coded_height", C.c_int32), ("frame_width", C.c_int32), ("frame_height", C.c_int32),
                 ("picture_rate", C.c_double), ("duration", C.c_double), ("gops", C.c_uint32), ("shard_gops", C.c_uint32),
                 ("first_gop", C.c_uint32), ("parser_threads", C.c_int32), ("gops_per_window", C.c_int32),
-                ("gpu_parser", C.c_int32), ("reserved", C.c_int32)]
+                ("gpu_parser", C.c_int32), ("display_flavour", C.c_int32)]
 
 
 class PipelineStats(C.Structure):
@@ -438,7 +438,7 @@ class Pipeline:
     released right after.  read_frame(frame) works until the frame's window is released."""
 
     def __init__(self, data, device_id=0, parser_threads=0, gops_per_window=0, windows_in_flight=0, max_gop_pictures=0,
-                 loop=0, on_window=None, shard_index=0, shard_count=0, start_seconds=0.0, gpu_parser=None, valid_bytes=None):
+                 loop=0, on_window=None, shard_index=0, shard_count=0, start_seconds=0.0, gpu_parser=None, valid_bytes=None, display_flavour=0):
         self.lib = load()
         self._data = (C.c_uint8 * len(data)).from_buffer_copy(data)      # must outlive the pipeline
         self._on_window = on_window
@@ -480,7 +480,7 @@ class Pipeline:
         self._cb = PIPELINE_CB(_cb)
         self._ready = ready
         cfg = PipelineConfig(device_id, parser_threads, gops_per_window, windows_in_flight, max_gop_pictures, loop,
-                             shard_index, shard_count, float(start_seconds), 0 if gpu_parser is None else (1 if gpu_parser else -1), 0)      # None: the library's default (the GPU)
+                             shard_index, shard_count, float(start_seconds), 0 if gpu_parser is None else (1 if gpu_parser else -1), int(display_flavour))      # None: the library's default (the GPU)
         h = C.c_void_p()
         self.h = None
         # valid_bytes: the stream is still arriving (leon_pipeline_create_partial); feed() reports progress

@@ -573,7 +573,7 @@ napi_value CreatePipeline(napi_env env, napi_callback_info info)
               get_i32(env, argv[1], "gopsPerWindow", &cfg.gops_per_window, 0) && get_i32(env, argv[1], "windowsInFlight", &cfg.windows_in_flight, 0) &&
               get_i32(env, argv[1], "maxGopPictures", &cfg.max_gop_pictures, 0) && get_i32(env, argv[1], "loop", &cfg.loop, 0) &&
               get_i32(env, argv[1], "shardIndex", &cfg.shard_index, 0) && get_i32(env, argv[1], "shardCount", &cfg.shard_count, 0) &&
-              get_i32(env, argv[1], "gpuParser", &cfg.gpu_parser, 0);
+              get_i32(env, argv[1], "gpuParser", &cfg.gpu_parser, 0) && get_i32(env, argv[1], "displayFlavour", &cfg.display_flavour, 0);
     {   // startSeconds: begin at the key-map entry at or before this time
         napi_value v;
         bool has = false;
