@@ -59,7 +59,9 @@ typedef struct leon_pipeline_config {
      *     a slice surface when its window completes.  The default since round 3: six times the host front end.
      *     A stream beyond the GPU parser's limits (a picture of more than ~40 k block groups -- larger than 4096 x 2304 --,
      *     a GOP shard of 2^28 bytes) is decoded on the parser threads under DEFAULT and refused under an explicit GPU
-     *     (leon_pipeline_info.gpu_parser says which it is).
+     *     (leon_pipeline_info.gpu_parser says which it is).  A picture whose slices OVERLAP (MPEG-1 forbids it; the
+     *     reference decodes them one after the other, the later one wins) is refused by the GPU parser, which decodes a
+     *     picture's slices side by side, when its window completes: the host parser decodes such a stream.
      *   LEON_PIPELINE_PARSER_HOST (-1): on the parser threads (libleon_vlc.so).
      * Same frames either way. */
     int32_t gpu_parser;

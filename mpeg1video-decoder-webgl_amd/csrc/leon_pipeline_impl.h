@@ -239,26 +239,29 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
     const size_t mbs = (size_t)p->vinfo.mb_width * p->vinfo.mb_height;
     const size_t mpad = pad256(mbs), vpad = pad256(mbs * 4), gpad = pad256(((size_t)p->vinfo.n_groups + 1) * 4);
     const size_t rpad = pad256(mbs * leon::kVlcMbRecBytes);
+    // the block records of a picture: one array for all its slices (leon_vlc_gpu.h VlcSliceOut), a record per block at most
+    const size_t recpad = pad256(mbs * (size_t)leon::vlc_blocks_per_mb(p->vinfo.has_alpha == 1) * leon::kVlcRecWords * 4);
     const size_t max_entries = (size_t)p->vinfo.coded_width * p->vinfo.coded_height * (p->vinfo.has_alpha == 1 ? 5 : 3) / 2;
     const size_t stream_pad = pad256(n + 16);
     // sizes first: the arena may move when it grows
     const size_t maps_per_pic = 4 * mpad + 2 * vpad;
-    size_t need = stream_pad + scans.size() * (rpad + maps_per_pic);
+    size_t need = stream_pad + scans.size() * (rpad + recpad + maps_per_pic);
     std::vector<size_t> ecap(scans.size());
-    std::vector<std::vector<size_t>> scap(scans.size());
     for (size_t k = 0; k < scans.size(); k++) {
         const Scan& x = scans[k];
         size_t pic_words = 0;
-        scap[k].resize(x.code.size());
         for (size_t j = 0; j < x.code.size(); j++) {
             const uint64_t begin = x.pos[j] >> 3, end = j + 1 < x.code.size() ? (x.pos[j + 1] >> 3) - 4 : x.s.end_byte;
             const size_t nb = end > begin ? (size_t)(end - begin) : 0;
-            scap[k][j] = nb;                             // bytes of the slice: its strip is sized from them below
-            pic_words += 4 * nb;
+            // An entry is a coefficient symbol, and n of them in a block take 3 n + 1 bits at least: the shortest code is
+            // '11s' (three bits; '1s', two, in first position only), and the end-of-block code (or an intra block's DC size
+            // code) another two -- entries <= bits / 3.  (Round 3 reserved a dword per two bits.)  The kernels keep inside
+            // the bound whatever the stream says (k_vlc_blocks, and the reconstruction reads the list through a buffer
+            // resource of exactly this length).
+            pic_words += (8 * nb) / 3 + 2;
         }
         ecap[k] = std::min(std::max(pic_words, (size_t)64), max_entries);
         need += gpad + pad256(ecap[k] * 4 + 4);
-        for (size_t c : scap[k]) need += pad256((2 * c + 8) * leon::kVlcRecWords * 4);
     }
     if (!arena_reserve(p, a_of(job), stream_pad, need)) { job->status = LEON_ERR_NOMEM; job->err = "staging allocation failed"; return; }
     Arena* a = job->arena;
@@ -302,6 +305,7 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
         v.grp_off = (uint32_t*)(dev + m.grp_off);
         v.entries = (uint32_t*)(dev + m.entries);
         v.entries_cap = (uint32_t)ecap[k];
+        v.recs = (uint32_t*)(dev + take(recpad));
         for (size_t j = 0; j < x.code.size(); j++) {
             leon::VlcSlice sl{};
             sl.bytes = (const uint32_t*)dev;
@@ -311,10 +315,6 @@ void scan_gop_for_gpu(leon_pipeline* p, GopJob* job, leon_vlc_stream* st, const 
             sl.end_byte = (uint32_t)(j + 1 < x.code.size() ? (x.pos[j + 1] >> 3) - 4 : x.s.end_byte);
             sl.code = x.code[j];
             sl.pic = (uint32_t)k;
-            // a coded block takes at least four bits (one header), an entry at least two
-            sl.hdr_cap = (uint32_t)(2 * scap[k][j] + 8);
-            sl.ent_cap = 0;
-            sl.scratch = (uint32_t*)(dev + take(pad256((size_t)sl.hdr_cap * leon::kVlcRecWords * 4)));
             job->slices.push_back(sl);
         }
     }
@@ -468,7 +468,7 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
     if (!n_slices || !n_pics) return LEON_OK;
     VlcRing& R = p->vlc_ring[(size_t)w->ring];
     const size_t desc_bytes = pad256(n_slices * sizeof(leon::VlcSlice)) + pad256(n_pics * sizeof(leon::VlcPic)) + pad256(w->jobs.size() * sizeof(leon::VlcClear));
-    const size_t dev_bytes = desc_bytes + pad256(n_slices * 4) + pad256(n_pics * 4);
+    const size_t dev_bytes = desc_bytes + pad256(n_slices * sizeof(leon::VlcSliceOut)) + pad256(n_pics * 4);
     if (dev_bytes > R.cap) {                     // the ring entry is ours: its previous window has been released
         if (R.h) hipHostFree(R.h);
         if (R.d) hipFree(R.d);
@@ -486,8 +486,8 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
     }
     leon::VlcSlice* hs = (leon::VlcSlice*)R.h;
     leon::VlcPic* hp = (leon::VlcPic*)(R.h + pad256(n_slices * sizeof(leon::VlcSlice)));
-    uint32_t* d_words = (uint32_t*)(R.d + desc_bytes);
-    uint32_t* d_err = (uint32_t*)(R.d + desc_bytes + pad256(n_slices * 4));
+    leon::VlcSliceOut* d_words = (leon::VlcSliceOut*)(R.d + desc_bytes);      // what k_vlc_parse leaves per slice for the two kernels behind it
+    uint32_t* d_err = (uint32_t*)(R.d + desc_bytes + pad256(n_slices * sizeof(leon::VlcSliceOut)));
     leon::VlcClear* hc = (leon::VlcClear*)(R.h + pad256(n_slices * sizeof(leon::VlcSlice)) + pad256(n_pics * sizeof(leon::VlcPic)));
     size_t pi = 0, ci = 0;
     // Slice order of the launch: picture by picture, the I pictures first, then P, then B -- the 64 lanes of a wave
@@ -536,7 +536,7 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
     const leon::VlcPic* dp = (const leon::VlcPic*)(R.d + pad256(n_slices * sizeof(leon::VlcSlice)));
     const int blocks = (int)((n_slices + 255) / 256);
     hipLaunchKernelGGL(leon::k_vlc_parse, dim3(blocks), dim3(256), 4 * leon::kVlcRingDwords * 64 * 4, vs, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
-    hipLaunchKernelGGL(leon::k_vlc_index, dim3((unsigned)n_pics), dim3(leon::kVlcIndexThreads), p->vlc_index_lds, vs, ds, d_words, dp, p->vgeom);
+    hipLaunchKernelGGL(leon::k_vlc_index, dim3((unsigned)n_pics), dim3(leon::kVlcIndexThreads), p->vlc_index_lds, vs, ds, d_words, dp, d_err, p->vgeom);
     hipLaunchKernelGGL(leon::k_vlc_blocks, dim3((unsigned)((n_slices + 3) / 4)), dim3(256), 0, vs, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(R.h_err, d_err, n_pics * 4, hipMemcpyDeviceToHost, vs));
@@ -852,7 +852,8 @@ void notify_main(leon_pipeline* p)
                 if (e[k]) {
                     static const char* const what[] = {"", "invalid macroblock address increment", "macroblock address outside the picture",
                         "invalid macroblock type", "invalid motion code", "invalid coded block pattern", "invalid coefficient code",
-                        "coefficient index overflow", "bitstream ends inside a slice", "invalid DC size code", "slice larger than its scratch strip"};
+                        "coefficient index overflow", "bitstream ends inside a slice", "invalid DC size code", "more block records than the picture has blocks",
+                                           "slices of a picture overlap (the GPU parser decodes them side by side: gpu_parser = -1 decodes such a stream)"};
                     const uint32_t code = e[k] & 255u;
                     w->status = LEON_ERR_INVALID;
                     pipe_fail(p, LEON_ERR_INVALID, std::string("window ") + std::to_string(w->id) + ", picture " + std::to_string(k) + ", slice " +
@@ -1152,18 +1153,20 @@ int leon_pipeline_create_partial(const leon_pipeline_config* cfg, const uint8_t*
     }
     if (p->gpu_parser) {
         // The arenas of the GPU parser come out of two slabs allocated HERE, sized for the largest GOP shard of the key
-        // map (what scan_gop_for_gpu will ask for, from its own bounds: 16 bytes of entry list and 32 of block records per
-        // stream byte, the maps and records of max_gop_pictures pictures, a strip per slice): allocated one by one at
+        // map (what scan_gop_for_gpu will ask for, from its own bounds: 32 / 3 bytes of entry list per stream byte -- an entry
+        // takes three bits at least --, the maps, macroblock records and block records of max_gop_pictures pictures; round 3
+        // asked for 48 bytes per stream byte, 35 GB at W = 128 in 1080p, round 4's bounds come to 15 GB): allocated one by one at
         // their first use -- and again when a larger GOP came by, hipFree waits for the device -- the first four windows of
         // a 1080p run took 35-40 ms each instead of 8.6.  A GOP that still does not fit gets an allocation of its own
         // (arena_reserve); without the memory for the slabs everything does.
         size_t largest = 0;
         for (uint64_t g : p->mine) largest = std::max(largest, (size_t)(p->shard_end[g] - p->shard_begin[g]));
         const size_t mbs = (size_t)p->vinfo.mb_width * p->vinfo.mb_height;
-        const size_t per_pic = pad256(mbs * leon::kVlcMbRecBytes) + 4 * pad256(mbs) + 2 * pad256(mbs * 4) + pad256(((size_t)p->vinfo.n_groups + 1) * 4) + 512 +
-                               2 * (size_t)p->vinfo.mb_height * 512;
+        const size_t per_pic = pad256(mbs * leon::kVlcMbRecBytes) + 4 * pad256(mbs) + 2 * pad256(mbs * 4) + pad256(((size_t)p->vinfo.n_groups + 1) * 4) + 1024 +
+                               pad256(mbs * (size_t)leon::vlc_blocks_per_mb(p->vinfo.has_alpha == 1) * leon::kVlcRecWords * 4) +
+                               8 * (size_t)p->vinfo.mb_height * 4;      // (+ 2 entries per slice: one slice per macroblock row is the common case, more find room in the lists' slack)
         const size_t host_each = pad256(largest + 16) + 4096;
-        const size_t dev_each = (pad256(largest + 16) + 48 * largest + (size_t)p->max_pics * per_pic + 65535) / 65536 * 65536;
+        const size_t dev_each = (pad256(largest + 16) + 11 * largest + (size_t)p->max_pics * per_pic + 65535) / 65536 * 65536;
         size_t free_b = 0, total_b = 0;
         if (hipMemGetInfo(&free_b, &total_b) == hipSuccess && (size_t)n_arenas * dev_each < free_b / 2 && !getenv("LEON_DEBUG_NO_SLABS")) {
             if (big_alloc((void**)&p->slab_dev, (size_t)n_arenas * dev_each, kBigArenas) == hipSuccess &&

@@ -16,7 +16,8 @@
 //                  macroblock), DC values, and for every coded block WHERE its coefficient symbols begin and how
 //                  many there are -- the symbols themselves are stepped over, several at a time (one table lookup on
 //                  12 bits gives the bits, the number of symbols and the positions they advance, up to the end of
-//                  block).  One 16-byte record per coded block into the slice's strip.  No atomics.
+//                  block).  One 16-byte record per coded block into the picture's record array, the slice's records
+//                  side by side from (first macroblock address x blocks per macroblock) on.  No atomics.
 //   k_vlc_index    one workgroup per picture: counts the entries of every group from the block records (LDS atomics;
 //                  a record learns its block's place inside the group), exclusive scan -> grp_off (what
 //                  leon_sparse_picture wants), and turns the macroblock records into the maps (whole lines).
@@ -104,6 +105,7 @@ struct VlcPic {                  // one picture of the window
     uint32_t* entries;
     uint32_t entries_cap;
     uint32_t n_slices;
+    uint32_t* recs;              // the block records of its slices: room for EVERY block of the picture (mbw * mbh * blocks per macroblock records)
 };
 
 struct VlcSlice {
@@ -114,13 +116,23 @@ struct VlcSlice {
     uint32_t end_byte;           // first byte behind the slice
     int32_t code;                // slice_vertical_position
     uint32_t pic;
-    uint32_t hdr_cap;            // block records the strip has room for
-    uint32_t ent_cap;            // (unused since round 3: the entries go straight to the picture's lists)
-    uint32_t* scratch;           // [hdr_cap records of kVlcRecWords dwords]
 };
 
+// Where a slice's block records lie (round 4).  Round 3 gave every slice a strip sized from its bytes (a coded block takes four
+// bits at least: 32 bytes of records per byte of stream, 3.3 MB per 1080p picture, 60 % of the arenas).  But the slices of a
+// picture do not overlap: slice s covers the macroblocks [first_s, last_s] with last_s < first_(s+1), and a macroblock has
+// `bpm` blocks at most -- so a slice that writes its records side by side from record first_s * bpm on ends in front of record
+// (last_s + 1) * bpm <= first_(s+1) * bpm, where the next slice begins: ONE array of mbs * bpm records per picture (0.78 MB at
+// 1080p) holds them all, whatever the stream, and a lane knows where its part begins as soon as it has read its first
+// macroblock address.  k_vlc_parse leaves {first record, end record, last macroblock address} per slice; k_vlc_index holds
+// last_s < first_(s+1) against them -- slices that overlap (MPEG-1 forbids it; the host parser decodes them one after the
+// other, the later one wins, as the reference does) would have written into each other's records, in an order nobody knows:
+// the picture is refused (VLC_ERR_OVERLAP) instead.
+struct VlcSliceOut { uint32_t first_rec, end_rec; int32_t last_mb; uint32_t pad; };
+__host__ __device__ inline int vlc_blocks_per_mb(int alpha) { return alpha ? 10 : 6; }
+
 enum { VLC_ERR_MBA = 1, VLC_ERR_ADDR, VLC_ERR_TYPE, VLC_ERR_MOTION, VLC_ERR_CBP, VLC_ERR_COEF, VLC_ERR_INDEX, VLC_ERR_END, VLC_ERR_DC,
-       VLC_ERR_SCRATCH };
+       VLC_ERR_SCRATCH, VLC_ERR_OVERLAP };
 
 // Requests dwords [loaded, upto) of a lane's stream into its ring slots: 16 conditional LDS-direct loads, one per
 // slot (the LDS address of such a load is wave-uniform: slot i of every lane that wants it goes in one instruction).
@@ -242,14 +254,28 @@ struct VlcCtx {                  // per lane: the state a slice carries from mac
     int fw_h, fw_v, fw_h_prev, fw_v_prev, bw_h, bw_v, bw_h_prev, bw_v_prev, prev_dir;
     int dc_y, dc_cr, dc_cb, dc_a, qs;
     int mb_intra;
-    VLC_G uint32_t* hdr;         // next free block record of the slice's strip
-    VLC_G uint32_t* hdr_end;
+    VLC_G uint32_t* hdr;         // next free block record of the slice (nullptr until its first macroblock address is known)
+    VLC_G uint32_t* hdr_end;     // end of the picture's record array
     VLC_G char* zbase;           // the picture's macroblock records
     int type, full_pel_fwd, fwd_rsize, full_pel_bwd, bwd_rsize;
     uint32_t* wave_ring;         // LDS ring of the wave (VlcWin::sync)
     int lane;
     uint32_t n_bytes, end_byte;  // lockstep loop: the slice's bounds for the end-of-slice test
+    const VlcPic* pics;          // (wave-uniform) for the one read of the picture's record array, at the slice's first macroblock
+    VLC_G uint32_t* outs;        // (wave-uniform) the launch's VlcSliceOut array
+    uint32_t pic;
 };
+
+// the slice's first macroblock address is known: its block records begin at record mb * (blocks per macroblock) of the
+// picture's array (see VlcSliceOut)
+__device__ __forceinline__ void vlc_first_macroblock(VlcCtx& c, const VlcGeom& G, int mb)
+{
+    const uint32_t bpm = (uint32_t)vlc_blocks_per_mb(G.alpha);
+    VLC_G uint32_t* const recs = (VLC_G uint32_t*)c.pics[c.pic].recs;
+    c.hdr = recs + (uint32_t)mb * bpm * kVlcRecWords;
+    c.hdr_end = recs + (uint32_t)(G.mbw * G.mbh) * bpm * kVlcRecWords;
+    c.outs[(blockIdx.x * 256u + threadIdx.x) * 4u] = (uint32_t)mb * bpm;
+}
 #define VLC_SYNC(r, c) (r).sync((c).wave_ring, (c).lane)
 
 // decoders/jsv.js:831-893, as motion_component of leon_vlc.cpp
@@ -423,6 +449,7 @@ __device__ __forceinline__ int vlc_macroblock(VlcWin& r, const VlcLds& L, const 
     }
     const int mb = c.mb_addr;
     if (mb < 0 || mb >= mbsize) return VLC_ERR_ADDR + 1;
+    if (c.hdr == nullptr) vlc_first_macroblock(c, G, mb);
     c.mb_col += mb - c.rc_addr;
     c.rc_addr = mb;
     while (c.mb_col >= G.mbw) { c.mb_col -= G.mbw; c.mb_row++; }
@@ -564,6 +591,7 @@ __device__ __forceinline__ void vlc_round_header(VlcWin& r, const VlcLds& L, con
     }
     const int mb = c.mb_addr;
     if (mb < 0 || mb >= mbsize) { l.err = VLC_ERR_ADDR; l.phase = VLC_PH_DONE; return; }
+    if (c.hdr == nullptr) vlc_first_macroblock(c, G, mb);
     c.mb_col += mb - c.rc_addr;
     c.rc_addr = mb;
     while (c.mb_col >= G.mbw) { c.mb_col -= G.mbw; c.mb_row++; }
@@ -723,7 +751,7 @@ __device__ __forceinline__ void vlc_round_coef(VlcWin& r, const VlcLds& L, VlcCt
 }
 
 // LDS (tables 18.4 KB + four rings of 4 KB per workgroup) allows four waves per SIMD: let the registers go that far too
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEON_VLC_WAVES, LEON_VLC_WAVES))) void k_vlc_parse(const VlcSlice* __restrict__ slices, uint32_t* __restrict__ slice_words, int n_slices,
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEON_VLC_WAVES, LEON_VLC_WAVES))) void k_vlc_parse(const VlcSlice* __restrict__ slices, VlcSliceOut* __restrict__ slice_out, int n_slices,
                                                    const VlcPic* __restrict__ pics, uint32_t* __restrict__ errors, VlcGeom G,
                                                    const VlcTables* __restrict__ T)
 {
@@ -755,8 +783,10 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEON_VLC_WA
     c.mb_col = -1;
     c.rc_addr = c.mb_addr;
     c.dc_y = c.dc_cr = c.dc_cb = c.dc_a = 128;
-    c.hdr = (VLC_G uint32_t*)S.scratch;
-    c.hdr_end = c.hdr + S.hdr_cap * kVlcRecWords;
+    c.hdr = c.hdr_end = nullptr;                              // until the first macroblock address is known (vlc_first_macroblock)
+    c.pics = pics;
+    c.outs = (VLC_G uint32_t*)slice_out;
+    c.pic = S.pic;
     c.qs = (int)r.get(5);
     for (;;) {                                                // extra_information_slice
         VLC_SYNC(r, c);
@@ -802,7 +832,15 @@ __global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(LEON_VLC_WA
         if (i >= S.end_byte) { err = VLC_ERR_END; break; }    // behind the start code the host found: ran over it
     }
 #endif
-    ((VLC_G uint32_t*)slice_words)[j] = (uint32_t)(c.hdr - (VLC_G uint32_t*)S.scratch) / kVlcRecWords;       // coded blocks of the slice
+    {   // where the slice's records end, and its last macroblock address (VlcSliceOut; .first_rec was written at its first macroblock)
+        VLC_G uint32_t* const o = (VLC_G uint32_t*)slice_out + (uint32_t)j * 4u;
+        if (c.hdr != nullptr) {
+            o[1] = (uint32_t)(G.mbw * G.mbh * vlc_blocks_per_mb(G.alpha)) - (uint32_t)(c.hdr_end - c.hdr) / kVlcRecWords;
+            o[2] = (uint32_t)c.mb_addr;
+        } else {
+            o[0] = 0u; o[1] = 0u; o[2] = 0xffffffffu;          // never got to a macroblock (an error word says why)
+        }
+    }
     if (err) atomicCAS(errors + S.pic, 0u, (uint32_t)err | ((uint32_t)S.code << 8));     // rare: a generic atomic is fine here
 }
 
@@ -825,21 +863,28 @@ __global__ __launch_bounds__(256) void k_vlc_clear(const VlcClear* __restrict__ 
 //    after lane along the macroblock address: whole lines.
 // Dynamic LDS: n_groups counters + a word per wave.
 static constexpr int kVlcIndexThreads = 256;      // small workgroups: beside the reconstruction launches a 1024-thread one waited for 16 free wave slots on ONE CU
-__global__ __launch_bounds__(kVlcIndexThreads) void k_vlc_index(const VlcSlice* __restrict__ slices, const uint32_t* __restrict__ slice_blocks,
-                                                                const VlcPic* __restrict__ pics, VlcGeom G)
+__global__ __launch_bounds__(kVlcIndexThreads) void k_vlc_index(const VlcSlice* __restrict__ slices, const VlcSliceOut* __restrict__ slice_out,
+                                                                const VlcPic* __restrict__ pics, uint32_t* __restrict__ errors, VlcGeom G)
 {
     extern __shared__ uint32_t s_index[];
     const int ng = G.n_groups, tid = (int)threadIdx.x, lane = tid & 63, wv = tid >> 6;
     uint32_t* const cnt = s_index;
     uint32_t* const part = s_index + ng;
     const VlcPic P = pics[blockIdx.x];
+    const uint32_t bpm = (uint32_t)vlc_blocks_per_mb(G.alpha), rec_cap = (uint32_t)(G.mbw * G.mbh) * bpm;
     for (int g = tid; g < ng; g += kVlcIndexThreads) cnt[g] = 0u;
     __syncthreads();
     // a wave per slice, a lane per record, four records of a lane in flight
     for (uint32_t sidx = (uint32_t)wv; sidx < P.n_slices; sidx += kVlcIndexThreads / 64) {
-        const VlcSlice* S = slices + P.first_slice + sidx;
-        const uint32_t n_blocks = min(slice_blocks[P.first_slice + sidx], S->hdr_cap);
-        uint32_t* const rec = S->scratch;
+        const VlcSliceOut O = slice_out[P.first_slice + sidx];
+        const uint32_t n_blocks = O.first_rec <= O.end_rec && O.end_rec <= rec_cap ? O.end_rec - O.first_rec : 0u;
+        uint32_t* const rec = P.recs + (size_t)O.first_rec * kVlcRecWords;
+        // the slices of a picture do not overlap (VlcSliceOut): the next one begins behind this one's last macroblock
+        if (lane == 0 && sidx + 1u < P.n_slices && O.last_mb >= 0) {
+            const VlcSliceOut N = slice_out[P.first_slice + sidx + 1u];
+            if (N.last_mb >= 0 && N.first_rec / bpm <= (uint32_t)O.last_mb)
+                atomicCAS(errors + blockIdx.x, 0u, (uint32_t)VLC_ERR_OVERLAP | ((uint32_t)slices[P.first_slice + sidx + 1u].code << 8));
+        }
         for (uint32_t b0 = (uint32_t)lane; b0 < n_blocks; b0 += 256) {
             uint32_t r1[4];
 #pragma unroll
@@ -911,7 +956,7 @@ __global__ __launch_bounds__(kVlcIndexThreads) void k_vlc_index(const VlcSlice* 
 // pairs until the end-of-block code and writes them as entries (tile offset << 16 | level) to grp_off[group] + its place.
 // Same symbol reading as leon_vlc.cpp's decode_block; a block that does not read the way k_vlc_parse counted it (it
 // cannot, both read the same bits with the same tables) sets the picture's error word instead of leaving entries undefined.
-__global__ __launch_bounds__(256) void k_vlc_blocks(const VlcSlice* __restrict__ slices, const uint32_t* __restrict__ slice_blocks, int n_slices,
+__global__ __launch_bounds__(256) void k_vlc_blocks(const VlcSlice* __restrict__ slices, const VlcSliceOut* __restrict__ slice_out, int n_slices,
                                                     const VlcPic* __restrict__ pics, uint32_t* __restrict__ errors, VlcGeom G,
                                                     const VlcTables* __restrict__ T)
 {
@@ -926,8 +971,10 @@ __global__ __launch_bounds__(256) void k_vlc_blocks(const VlcSlice* __restrict__
     if (j >= n_slices) return;
     const VlcSlice S = slices[j];
     const VlcPic P = pics[S.pic];
-    const uint32_t n_blocks = min(slice_blocks[j], S.hdr_cap);
-    const VLC_G uint32_t* const rec = (const VLC_G uint32_t*)S.scratch;
+    const VlcSliceOut O = slice_out[j];
+    const uint32_t rec_cap = (uint32_t)(G.mbw * G.mbh * vlc_blocks_per_mb(G.alpha));
+    const uint32_t n_blocks = O.first_rec <= O.end_rec && O.end_rec <= rec_cap ? O.end_rec - O.first_rec : 0u;
+    const VLC_G uint32_t* const rec = (const VLC_G uint32_t*)P.recs + (size_t)O.first_rec * kVlcRecWords;
     const VLC_G uint32_t* const bytes = (const VLC_G uint32_t*)S.bytes;
     const VLC_G uint32_t* const grp_off = (const VLC_G uint32_t*)P.grp_off;
     VLC_G uint32_t* const entries = (VLC_G uint32_t*)P.entries;

@@ -169,3 +169,64 @@ def test_a_picture_whose_group_counters_need_more_than_64_kb_of_lds(L):
     want = oracle_frames(data)
     for k in ((0, 2), (0, 5), (0, 3)):
         assert np.array_equal(gpu[k].reshape(-1), np.asarray(want[k]).reshape(-1)), k
+
+
+def _stream_of_shortest_codes(cw, ch):
+    """I B B P B B (coded order I B B P B B of S.gop_ibbp) whose every coefficient is +-1 at every position: a coded block is 64 symbols of three bits ('11s';
+    '1s' in first position) -- the densest stream of entries the syntax allows: what the GPU parser's arenas are sized for
+    (an entry per three bits; csrc/leon_pipeline_impl.h scan_gop_for_gpu)"""
+    import jsv_writer as W
+    import synth as S
+    rng = np.random.default_rng(77)
+    pics = []
+    for ptype, disp, f, b in S.gop_ibbp(6):
+        t = S.make_picture(rng, cw, ch, ptype, intra_frac=0.05, skip_frac=0.0, uncoded_frac=0.0,
+                           force_dir=2 if (ptype == S.PIC_B and f is None) else None)
+        for name in ("coef_y", "coef_cb", "coef_cr"):
+            sign = rng.integers(0, 2, size=t[name].shape) * 2 - 1
+            t[name] = sign.astype(t[name].dtype)
+        t["display"] = disp
+        pics.append(t)
+    return W.write_stream(pics, cw, ch, cw, ch, gop_starts=[0])[0]
+
+
+def test_the_densest_stream_the_syntax_allows_fits_the_entry_lists(L):
+    data = _stream_of_shortest_codes(96, 64)
+    want = oracle_frames(data)
+    host, _, hstats = run_pipeline(L, data, parser_threads=1, gops_per_window=1)
+    # the premise: close to an entry per three bits of stream (container, headers and macroblock layers included)
+    assert hstats["entries"] * 3.0 / (8 * len(data)) > 0.9, (hstats["entries"], len(data))
+    gpu, _, _ = run_pipeline(L, data, parser_threads=1, gops_per_window=1, gpu_parser=True)
+    assert set(gpu) == set(want) == set(host)
+    for k in want:
+        assert np.array_equal(host[k], want[k]), k
+        assert np.array_equal(gpu[k], want[k]), k
+
+
+def test_overlapping_slices_are_refused_by_the_gpu_parser_and_decoded_by_the_host_parser(L):
+    """MPEG-1 forbids slices that overlap; the reference (and the host parser) decode them one after the other, the later
+    one wins.  On the GPU the slices of a picture are decoded side by side and write their block records side by side
+    (leon_vlc_gpu.h VlcSliceOut): such a picture is refused, deterministically, instead of decoded in an order nobody knows.
+    The stream: the second slice of the first picture renamed to row 1."""
+    good = ibbp_stream(96, 64, [3, 3], seed=5)
+    at = good.find(b"\x00\x00\x01\x02")
+    assert at > 0 and good[:at].count(b"\x00\x00\x01\x01") == 1
+    bad = bytearray(good)
+    bad[at + 3] = 1
+    bad = bytes(bad)
+    want = oracle_frames(bad)                    # the host front end + the oracle: the renamed slice overwrites row 1, row 2 stays empty
+    host, _, _ = run_pipeline(L, bad, parser_threads=1, gops_per_window=2)
+    assert set(host) == set(want)
+    for k in want:
+        assert np.array_equal(host[k], want[k]), k
+    pipe = L.Pipeline(bad, gops_per_window=2, parser_threads=1, gpu_parser=True)
+    try:
+        with pytest.raises(L.LeonError, match="overlap"):
+            pipe.wait()
+    finally:
+        pipe.close()
+    # and the untouched stream decodes
+    gpu, _, _ = run_pipeline(L, good, parser_threads=1, gops_per_window=2, gpu_parser=True)
+    want = oracle_frames(good)
+    for k in want:
+        assert np.array_equal(gpu[k], want[k]), k

@@ -19,6 +19,7 @@ for name in args:
     out = subprocess.run([sys.executable, os.path.join(root, "tools", "pipeline_bench.py")] + extra, env=env, capture_output=True, text=True)
     try:
         d = json.loads(out.stdout.strip().splitlines()[-1])
-        print("%-12s %7.0f pictures/s  %.2f s  scan %5.0f /thread/s  window %d" % (name, d["value"], d["seconds"], d["parser_pictures_per_s_per_thread"], d["gops_per_window"]), flush=True)
+        print("%-12s %7.0f pictures/s  %.2f s  scan %5.0f /thread/s  window %d  device %.1f GB" % (name, d["value"], d["seconds"], d["parser_pictures_per_s_per_thread"], d["gops_per_window"],
+                                                                                                    d.get("device_gb_held_by_the_pipeline") or 0.0), flush=True)
     except Exception as e:
         print(name, "FAILED", e, out.stderr[-500:], flush=True)

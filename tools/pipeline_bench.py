@@ -41,9 +41,18 @@ def main():
     else:
         import parse_bench
         data = parse_bench.make_stream(a.gops, "/tmp/leon_parse_bench_%d.jsv" % a.gops)
+    import ctypes
     import leon_ctypes as L
+    L.load()
+
+    def free_device_bytes():                      # what the pipeline holds on the device = free before - free after its creation
+        hip = ctypes.CDLL("libamdhip64.so")
+        f, t = ctypes.c_size_t(), ctypes.c_size_t()
+        return f.value if hip.hipMemGetInfo(ctypes.byref(f), ctypes.byref(t)) == 0 else None
+    free0 = free_device_bytes()
     t0 = time.perf_counter()
     pipe = L.Pipeline(data, parser_threads=a.threads, gops_per_window=a.window, windows_in_flight=a.inflight, loop=a.loop, gpu_parser=a.gpu_parser)
+    free1 = free_device_bytes()
     pipe.wait()
     wall = time.perf_counter() - t0
     s = pipe.stats()
@@ -55,6 +64,7 @@ def main():
         "value": s["pictures"] / s["seconds"], "macroblocks_per_s": s["pictures"] * mbs / s["seconds"],
         "pictures": s["pictures"], "seconds": s["seconds"], "wall_seconds_incl_setup": wall, "windows": s["windows"],
         "slice_layer": "GPU (csrc/leon_vlc_gpu.h)" if a.gpu_parser else "host threads (libleon_vlc.so)",
+        "device_gb_held_by_the_pipeline": (free0 - free1) / 1e9 if free0 is not None and free1 is not None else None,
         "parser_threads": pipe.info.parser_threads, "gops_per_window": pipe.info.gops_per_window,
         "parse_seconds_summed_over_threads": s["parse_seconds_sum"],
         "parser_pictures_per_s_per_thread": s["pictures"] / s["parse_seconds_sum"] if s["parse_seconds_sum"] else None,
