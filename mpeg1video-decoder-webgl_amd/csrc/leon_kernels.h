@@ -143,6 +143,19 @@ static constexpr int kOffTileR = Lay<1>::tile_r;
 #ifndef LEON_NINTH_FROM_BELOW
 #define LEON_NINTH_FROM_BELOW 1
 #endif
+#ifndef LEON_PRIO
+#define LEON_PRIO 0        // experiment (round 4): wave priority by progress through a display task, all picture types (1: rising, 2: falling)
+#endif
+#ifndef LEON_PRIO_B
+#define LEON_PRIO_B 3      // B display tasks: a wave starts at priority 3 and drops to 0 (2: after its chroma part, 3: when the luma parts' coefficient
+                          // loads are out, 4: after their column pass, 5: before the second luma part) -- young waves first: their loads are on the way
+                          // while the older ones compute.  One box, alternating, ms per mixed B launch: 1.027-1.031 without, 0.992-0.993 with 3 (4: the
+                          // same, 5: 1.018, 2: 0.998-1.004); the step 5.83-5.85 -> 5.73-5.75 ms.  For ALL types (LEON_PRIO=2) I and P got slower.
+#endif
+#ifndef LEON_PRIO_P
+#define LEON_PRIO_P 0
+#endif
+#define LEON_PRIO_OF(TYPE) (LEON_PRIO ? LEON_PRIO : ((TYPE) == 3 ? LEON_PRIO_B : (TYPE) == 2 ? LEON_PRIO_P : 0))      // (recon_luma_pair is the dense, non-alpha path only)
 #ifndef LEON_RGBA_AUX
 #define LEON_RGBA_AUX 2    // cache policy bits of the frames' stores (1 sc0, 2 nt, 16 sc1).  nt: the GPU never reads a frame again, and written
                           // through the caches like everything else it pushes the reference planes out -- round 4, one box, alternating: 5.944 ->
@@ -1145,6 +1158,7 @@ __device__ __forceinline__ void recon_luma_pair(const PicDesc& pd, const Geom& G
         coef_rows_to_lds(pd.coef[0], tileR, voff, 0u);
         coef_rows_to_lds(pd.coef[0], tileR + kLdsHalf, voff, 16u * (uint32_t)W);
     }
+    if (LEON_PRIO_OF(TYPE) == 3) __builtin_amdgcn_s_setprio(0);
     // quantiser scale | intra << 8 of the macroblock of block b of either part, in lane b (the chroma part's lanes hold the task's
     // eight macroblocks: lane m, macroblock m)
     const int qiaL = __builtin_amdgcn_ds_bpermute((lo3 >> 1) << 2, (int)carry.flags) & 0x11f;
@@ -1160,12 +1174,15 @@ __device__ __forceinline__ void recon_luma_pair(const PicDesc& pd, const Geom& G
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     column_pass<true, false>(lds, (uint32_t)kOffTileR, lds + Lay<1>::slots, reinterpret_cast<const char*>(pd.qt), n_cols, qiaL, qiaR, lane);
+    if (LEON_PRIO_OF(TYPE) == 4) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     dsp.side = 0;
     recon_task<TYPE, false, false, true, 0, 2, true, 1>(pd, G, Rt, 2 * gc, lds, lane, dsp, carry, false, lds, liveL[0], liveL[1]);
     if (has_right) {
+        if (LEON_PRIO_OF(TYPE) == 1) __builtin_amdgcn_s_setprio(3);
+        if (LEON_PRIO_OF(TYPE) == 5) __builtin_amdgcn_s_setprio(0);
         dsp.side = 1;
         recon_task<TYPE, false, false, true, 0, 2, true, 1>(pd, G, Rt, 2 * gc + 1, lds, lane, dsp, carry, false, tileR, liveR[0], liveR[1]);
     }
@@ -1270,6 +1287,8 @@ __device__ __forceinline__ bool display_task(const PicDesc* __restrict__ descs, 
     if (live) recon_task<TYPE, true, SPARSE, true, 0, LEON_CARRY ? 1 : 0, false, kPair ? 1 : 0>(pd, G, Rt, gc, lds, lane, dsp, carry);
     if (first) __syncthreads();          // the conversion tables have landed
     if (!live) return false;
+    if (kPair && LEON_PRIO_OF(TYPE) == 1) __builtin_amdgcn_s_setprio(1);
+    if (kPair && LEON_PRIO_OF(TYPE) == 2) __builtin_amdgcn_s_setprio(0);
     // the two luma parts as two calls, not a loop: the loop form keeps 15 more registers live (B path: 93).
     // yuva: the A part of the same four macroblocks first (AMODE 1), then the Y part that displays them (AMODE 2).
     if constexpr (kPair) {
@@ -1301,6 +1320,9 @@ void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
                                                                     const Tables* __restrict__ T)
 {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    // (the dense, non-alpha kernels only: in the pipeline's sparse launches a raised priority takes issue slots from the parser
+    // kernels beside them -- 175-177 k against 181-182 k pictures/s end to end)
+    if ((LEON_PAIR_LUMA && LEON_CARRY && !SPARSE && !ALPHA && TYPE != 1) && LEON_PRIO_OF(TYPE) >= 2) __builtin_amdgcn_s_setprio(3);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int lane0 = threadIdx.x & 63;
     const int wg = xcd_remap(blockIdx.x, G.n_wg);
