@@ -1190,10 +1190,15 @@ __device__ __forceinline__ void recon_luma_pair(const PicDesc& pd, const Geom& G
 
 // A wave's copy of the quantiser matrices and the premultiplier (the first 64 dwords of Tables; the column pass
 // reads them by the column its lane was handed): one load and one LDS write per lane, once per wave.
+// Straight into LDS (lane i's dword at kOffQtab + 4 i), nothing waits here: through a register (round 1-4: load, s_waitcnt vmcnt(0),
+// ds_write) the wave made a round trip to memory before it requested its first coefficient row.  The tables are read by the column
+// pass, behind the task's wait for its coefficient rows (dense: wait_vmem_all) or first entries (sparse; loads return in order).
 __device__ __forceinline__ void stage_tables(const QTables* __restrict__ Tg, char* lds, int lane)
 {
-    const uint32_t v = reinterpret_cast<const LEON_GLOBAL uint32_t*>(gptr(Tg))[lane];
-    reinterpret_cast<uint32_t*>(lds + kOffQtab)[lane] = v;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)Tg, 0, 256, 0x00020000);
+    // (the matrices and the premultiplier only: the 64 bytes behind them are the display task's vectors in LDS, kOffCarry, written
+    // by the chroma part -- which a load that lands late must not overwrite)
+    if (lane < 48) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (__attribute__((address_space(3))) void*)(lds + kOffQtab), 4, lane * 4, 0, 0, 0);
 }
 
 // XCD-aware workgroup remap: hardware deals workgroups round-robin over the 8 XCDs;
@@ -1285,7 +1290,10 @@ __device__ __forceinline__ bool display_task(const PicDesc* __restrict__ descs, 
     }
     MbCarry carry{};
     if (live) recon_task<TYPE, true, SPARSE, true, 0, LEON_CARRY ? 1 : 0, false, kPair ? 1 : 0>(pd, G, Rt, gc, lds, lane, dsp, carry);
-    if (first) __syncthreads();          // the conversion tables have landed
+    if (first) {
+        if (!live) wait_vmem_all();      // (a wave with a task has waited for memory behind its chroma part's loads: its chunks of the tables are in)
+        __syncthreads();                 // the conversion tables have landed: every wave's chunks
+    }
     if (!live) return false;
     if (kPair && LEON_PRIO_OF(TYPE) == 1) __builtin_amdgcn_s_setprio(1);
     if (kPair && LEON_PRIO_OF(TYPE) == 2) __builtin_amdgcn_s_setprio(0);
@@ -1330,17 +1338,21 @@ void k_recon_display(const PicDesc* __restrict__ descs, Geom G,
     pic_of_wg<TYPE>(G, wg, pic, twg);
     const int wpw = (int)(blockDim.x >> 6);
     // the conversion tables: 5 KB per workgroup, requested before anything else and needed only after the
-    // chroma part -- the barrier in display_task finds them long landed.  Every wave takes part, with or without a task.
+    // chroma part -- the barrier in display_task finds them long landed.  Straight into LDS, 1 KB per instruction (lane i's 16
+    // bytes at chunk + 16 i), the chunks dealt to the workgroup's waves: nothing waits for them here.  (Until round 4 the
+    // tables went through registers: load, s_waitcnt vmcnt(0), ds_write -- a round trip to memory at the head of EVERY
+    // workgroup, in front of its first coefficient load; a workgroup of the B kernel lives 24 us.)  A wave's chunks have landed
+    // when its next full wait for memory returns: the chroma part's, behind its coefficient loads (dense) or first entries
+    // (sparse; loads return in order) -- a wave without a task waits in display_task -- and the barrier there makes every
+    // wave's chunks everybody's.
     __shared__ __attribute__((aligned(16))) int32_t lut_s[kLdsLut / 4];      // static: its LDS address is a compile-time constant
     {
-        const int32_t LEON_GLOBAL* src = gptr(T->rgba_lut);
-        int32_t* dst = lut_s;
-        int32_t v[5];
-        const uint32_t nt = blockDim.x;
-#pragma unroll
-        for (int k = 0; k < 5; k++) v[k] = threadIdx.x + nt * k < (uint32_t)(kLdsLut / 4) ? src[threadIdx.x + nt * k] : 0;
-#pragma unroll
-        for (int k = 0; k < 5; k++) if (threadIdx.x + nt * k < (uint32_t)(kLdsLut / 4)) dst[threadIdx.x + nt * k] = v[k];
+        static_assert(kLdsLut % 1024 == 0, "whole chunks");
+        const __amdgpu_buffer_rsrc_t lrs = __builtin_amdgcn_make_buffer_rsrc((void*)T->rgba_lut, 0, kLdsLut, 0x00020000);
+        const int n_waves = (int)(blockDim.x >> 6);
+        for (int c = wave; c < kLdsLut / 1024; c += n_waves)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(lrs, (__attribute__((address_space(3))) void*)(reinterpret_cast<char*>(lut_s) + c * 1024), 16,
+                                                     (int)(lane0 * 16u), c * 1024, 0, 0);
     }
     constexpr bool kPair = LEON_PAIR_LUMA && LEON_CARRY && !SPARSE && !ALPHA && TYPE != 1;
     char* lds = smem + wave * (ALPHA ? kLdsPerWaveDisplayAlpha : (kPair ? kLdsPerWaveDisplayPair : kLdsPerWaveDisplay));
