@@ -233,7 +233,10 @@ inline bool alpha_geom(const leon_decoder* d) { return d->geom.alpha != 0; }
 // each get in each other's way in L2 (dense boundary; the SPARSE kernels keep their occupancy: in the pipeline they share the CUs with
 // the parser's 35 KB workgroups, and padded they cost it 8-10 % end to end); the B launches (bound by their instruction count) are indifferent between 7 and 6 (1.045 / 1.038
 // ms) and lose 7 % at 5.  So: I and P at 5 workgroups per CU (20 KB + 11.5 KB of LDS per workgroup), B as the registers allow.
-constexpr size_t kOccupancyPadI = 11776, kOccupancyPadP = 11776, kOccupancyPadB = 0;
+// Measured again at the end of round 4, when a workgroup no longer began with a round trip to memory for its tables:
+// the I launch 0.382-0.384 ms at 5 workgroups per CU, **0.352 at 6**, 0.359 at 7
+// -- 6 it is (20 KB + 6 KB).  P (the two-tile kernel: launch_recon_type's own pad) is the same at 5 and 6.
+constexpr size_t kOccupancyPadI = 6144, kOccupancyPadP = 11776, kOccupancyPadB = 0;
 
 int n_groups_of(const Geom& G) { return 2 * G.tasksY + 2 * G.tasksC + (G.alpha ? 2 * G.tasksY : 0); }
 

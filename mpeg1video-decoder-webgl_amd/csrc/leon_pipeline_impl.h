@@ -535,7 +535,9 @@ int launch_gpu_parser(leon_pipeline* p, PipeWindow* w)
     const leon::VlcSlice* ds = (const leon::VlcSlice*)R.d;
     const leon::VlcPic* dp = (const leon::VlcPic*)(R.d + pad256(n_slices * sizeof(leon::VlcSlice)));
     const int blocks = (int)((n_slices + 255) / 256);
-    hipLaunchKernelGGL(leon::k_vlc_parse, dim3(blocks), dim3(256), 4 * leon::kVlcRingDwords * 64 * 4, vs, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
+    // LEON_DEBUG_VLC_LDS_PAD (bytes): more dynamic LDS for the slice loop's workgroups than they use -- what the reconstruction beside them loses to the parser's LDS
+    static const size_t vlc_lds_pad = getenv("LEON_DEBUG_VLC_LDS_PAD") ? (size_t)atol(getenv("LEON_DEBUG_VLC_LDS_PAD")) : 0;
+    hipLaunchKernelGGL(leon::k_vlc_parse, dim3(blocks), dim3(256), 4 * leon::kVlcRingDwords * 64 * 4 + vlc_lds_pad, vs, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
     hipLaunchKernelGGL(leon::k_vlc_index, dim3((unsigned)n_pics), dim3(leon::kVlcIndexThreads), p->vlc_index_lds, vs, ds, d_words, dp, d_err, p->vgeom);
     hipLaunchKernelGGL(leon::k_vlc_blocks, dim3((unsigned)((n_slices + 3) / 4)), dim3(256), 0, vs, ds, d_words, (int)n_slices, dp, d_err, p->vgeom, p->d_vlc_tables);
     HIP_TRY(hipGetLastError());
