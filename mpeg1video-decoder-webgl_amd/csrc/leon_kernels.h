@@ -737,9 +737,14 @@ __device__ __forceinline__ uint32_t scan_tile(const char* tile, char* ids, int l
 // The column pass (COL_INT_3 / COL_INT_5, decoders/shaders/mpeg1video.js:19-24) over the n_cols live columns listed in `ids`:
 // lane k takes the k-th; the results replace the coefficients in place.  PAIR: ids may name the second tile (tile0 + tile_step),
 // whose blocks' quantiser scale and intra flag sit in qia1 (lane b: block b's) as the first tile's in qia0.
-// TLDS: the tables are the wave's LDS copy at `qtab`; else `qtab` is the picture's QTables in memory.
+// TLDS: the tables are the wave's LDS copy at `qtab`; else they are in `qreg`: the picture's QTables, 256 bytes, dword i in lane i
+// -- a lane fetches the two dwords of its column's matrix row and of its premultiplier row with four ds_bpermute.  (Until the end of
+// round 4 the two-tile layout, which has no room for the tables in LDS, read them from memory inside this loop: two loads and an
+// `s_waitcnt vmcnt(0)` per round -- and loads return in order: the chroma part's wait for its tables was a wait for the REFERENCE
+// rows it had requested just before, whose flight the column pass was meant to cover.)
 template <bool PAIR, bool TLDS = true>
-__device__ __forceinline__ void column_pass(char* tile0, uint32_t tile_step, const char* ids, const char* qtab, uint32_t n_cols, int qia0, int qia1, int lane)
+__device__ __forceinline__ void column_pass(char* tile0, uint32_t tile_step, const char* ids, const char* qtab, uint32_t n_cols, int qia0, int qia1, int lane,
+                                            uint32_t qreg = 0u)
 {
     // the clamp bounds live in registers (v_med3 takes no literals on gfx950, and the compiler would
     // otherwise re-materialise them in front of every use): one scalar, one vector -- a VOP3
@@ -770,9 +775,11 @@ __device__ __forceinline__ void column_pass(char* tile0, uint32_t tile_step, con
             msel = *reinterpret_cast<const v2u*>(qt + (bia ? 0 : 64));
             pm8 = *reinterpret_cast<const v2u*>(qt + 128);
         } else {
-            const uint32_t qo = (id & 56u) + (bia ? 0u : 64u);
-            msel = ldg<v2u>(gptr(qtab), qo);
-            pm8 = ldg<v2u>(gptr(qtab), (id & 56u) + 128u);
+            const int qo = (int)((id & 56u) + (bia ? 0u : 64u)), po = (int)((id & 56u) + 128u);      // byte offsets = 4 x the lane that holds the dword
+            msel.x = (uint32_t)__builtin_amdgcn_ds_bpermute(qo, (int)qreg);
+            msel.y = (uint32_t)__builtin_amdgcn_ds_bpermute(qo + 4, (int)qreg);
+            pm8.x = (uint32_t)__builtin_amdgcn_ds_bpermute(po, (int)qreg);
+            pm8.y = (uint32_t)__builtin_amdgcn_ds_bpermute(po + 4, (int)qreg);
         }
         int nim = bia ? 0 : -1;
         asm("" : "+v"(nim));                              // keep it a mask (v_and), not a select
@@ -828,7 +835,7 @@ struct MbCarry { uint32_t flags; };       // q | intra << 8 | repadd >= 128 << 9
 // been through the column pass already; `live_in` says which of its columns were live
 template <int TYPE, bool CHROMA, bool SPARSE, bool DISPLAY, int AMODE = 0, int CARRY = 0, bool BACK = false, int LAYOUT = 0>
 __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int Rt, int g, char* lds, int lane, Display dsp, MbCarry& carry, bool alpha = false,
-                                           char* tile_in = nullptr, uint64_t live_in0 = 0, uint64_t live_in1 = 0)
+                                           char* tile_in = nullptr, uint64_t live_in0 = 0, uint64_t live_in1 = 0, uint32_t qreg = 0u)
 {
     char* const tile = BACK ? tile_in : lds;
     const int W = CHROMA ? G.cw >> 1 : G.cw;
@@ -1011,7 +1018,7 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         column_pass<false, Lay<LAYOUT>::tables_in_lds>(tile, 0u, lds + Lay<LAYOUT>::slots, Lay<LAYOUT>::tables_in_lds ? lds + kOffQtab : reinterpret_cast<const char*>(pd.qt),
-                                                       n_cols, qia, qia, lane);
+                                                       n_cols, qia, qia, lane, qreg);
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1138,7 +1145,8 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
 // part runs its back half (maps from the chroma part, reference fetches, row passes, prediction, stores, conversion) as before.
 // I pictures keep a front per part: with ~40 live columns per part the shared pass would run twice anyway.
 template <int TYPE>
-__device__ __forceinline__ void recon_luma_pair(const PicDesc& pd, const Geom& G, int Rt, int gc, char* lds, int lane, Display dsp, MbCarry& carry, bool has_right)
+__device__ __forceinline__ void recon_luma_pair(const PicDesc& pd, const Geom& G, int Rt, int gc, char* lds, int lane, Display dsp, MbCarry& carry, bool has_right,
+                                                uint32_t qreg)
 {
     const int W = G.cw, hi3 = lane >> 3, lo3 = lane & 7;
     char* const tileR = lds + kOffTileR;
@@ -1173,7 +1181,7 @@ __device__ __forceinline__ void recon_luma_pair(const PicDesc& pd, const Geom& G
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    column_pass<true, false>(lds, (uint32_t)kOffTileR, lds + Lay<1>::slots, reinterpret_cast<const char*>(pd.qt), n_cols, qiaL, qiaR, lane);
+    column_pass<true, false>(lds, (uint32_t)kOffTileR, lds + Lay<1>::slots, nullptr, n_cols, qiaL, qiaR, lane, qreg);
     if (LEON_PRIO_OF(TYPE) == 4) __builtin_amdgcn_s_setprio(0);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
@@ -1289,7 +1297,11 @@ __device__ __forceinline__ bool display_task(const PicDesc* __restrict__ descs, 
         stage_tables(pd.qt, lds, lane);
     }
     MbCarry carry{};
-    if (live) recon_task<TYPE, true, SPARSE, true, 0, LEON_CARRY ? 1 : 0, false, kPair ? 1 : 0>(pd, G, Rt, gc, lds, lane, dsp, carry);
+    // the two-tile layout has no room for the quantiser tables in LDS: the wave keeps them in ONE register, dword i of the 256 bytes
+    // in lane i (column_pass takes what it needs by ds_bpermute); requested first, landed with the macroblock maps
+    uint32_t qreg = 0u;
+    if constexpr (kPair) qreg = ldg<uint32_t>(gptr(pd.qt), (uint32_t)lane * 4u);
+    if (live) recon_task<TYPE, true, SPARSE, true, 0, LEON_CARRY ? 1 : 0, false, kPair ? 1 : 0>(pd, G, Rt, gc, lds, lane, dsp, carry, false, nullptr, 0, 0, qreg);
     if (first) {
         if (!live) wait_vmem_all();      // (a wave with a task has waited for memory behind its chroma part's loads: its chunks of the tables are in)
         __syncthreads();                 // the conversion tables have landed: every wave's chunks
@@ -1300,7 +1312,7 @@ __device__ __forceinline__ bool display_task(const PicDesc* __restrict__ descs, 
     // the two luma parts as two calls, not a loop: the loop form keeps 15 more registers live (B path: 93).
     // yuva: the A part of the same four macroblocks first (AMODE 1), then the Y part that displays them (AMODE 2).
     if constexpr (kPair) {
-        recon_luma_pair<TYPE>(pd, G, Rt, gc, lds, lane, dsp, carry, 2 * gc + 1 < G.gY);
+        recon_luma_pair<TYPE>(pd, G, Rt, gc, lds, lane, dsp, carry, 2 * gc + 1 < G.gY, qreg);
         return true;
     }
     dsp.side = 0;
