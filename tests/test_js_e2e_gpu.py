@@ -143,3 +143,21 @@ def test_native_pipeline_from_node_delivers_the_oracles_frames(name, gpu_parser)
         assert f["sha256"] == _sha(want[(f["gop"], f["displayIndex"])]), (f["gop"], f["displayIndex"])
     order = [(f["gop"], f["displayIndex"]) for f in got["frames"]]
     assert order == sorted(order)
+
+
+def test_native_pipeline_from_node_in_the_gl_display_flavour():
+    """{displayFlavour: 1} through the addon: the frames of the pipeline in the arithmetic of the reference's live display
+    (player/parts/end.js:77-156) -- equal to the oracle's GL flavour on the oracle's planes (tests/test_pipeline_gl_flavour_gpu.py
+    holds that flavour against the executed reference's canvas)"""
+    import json
+    import subprocess
+    from test_pipeline_gl_flavour_gpu import oracle_gl_frames
+    path = os.path.join(STREAMS, "slices5_ip_96x64.jsv")
+    want, _ = oracle_gl_frames(open(path, "rb").read())
+    out = subprocess.run(["node", os.path.join(ROOT, "tools", "js_pipeline_bench.js"), path, "--hash", "--threads", "2", "--window", "1", "--gl"],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["pictures"] == len(want) == len(got["frames"])
+    for f in got["frames"]:
+        assert f["sha256"] == _sha(want[(f["gop"], f["displayIndex"])]), (f["gop"], f["displayIndex"])

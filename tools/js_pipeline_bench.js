@@ -4,9 +4,10 @@
  * js_pipeline_bench.js -- the native pipeline driven from Node: the JavaScript thread starts it and then
  * only receives 'frames' events (napi_threadsafe_function); an interval timer counts how often the event
  * loop got to run meanwhile (the reference's page would be frozen inside decodeFrame for the duration).
- *   node tools/js_pipeline_bench.js <stream.jsv> [--loop 64] [--threads 16] [--window 32] [--hash]
+ *   node tools/js_pipeline_bench.js <stream.jsv> [--loop 64] [--threads 16] [--window 32] [--hash] [--gl]
  *        [--device d --shard-index r --shard-count N]   (one process per GPU: tools/js_multi_gpu.js)
  * --hash: print the sha256 of every frame instead (tests; small streams).
+ * --gl: displayFlavour 1 -- the frames in the fp32 arithmetic of the page's renderFrameGL (include/leon_pipeline.h).
  */
 const fs = require('fs');
 const path = require('path');
@@ -25,7 +26,7 @@ const t0 = process.hrtime.bigint();
 const p = new LeonPipeline(stream, { parserThreads: opt('--threads', 0), gopsPerWindow: opt('--window', 0),
                                      windowsInFlight: opt('--inflight', 0), loop: opt('--loop', 0), autoRelease: !hash,
                                      deviceId: opt('--device', 0), shardIndex: opt('--shard-index', 0), shardCount: opt('--shard-count', 0),
-                                     gpuParser: process.argv.includes('--gpu-parser') ? 1 : -1 });
+                                     gpuParser: process.argv.includes('--gpu-parser') ? 1 : -1, displayFlavour: args.includes('--gl') ? 1 : 0 });
 p.on('frames', (w, fs_) => {
   windows++;
   frames += fs_.length;
