@@ -1139,6 +1139,155 @@ __device__ __forceinline__ void recon_task(const PicDesc& pd, const Geom& G, int
     }
 }
 
+// ---- the back half of a luma part of recon_luma_pair as two functions (LEON_EARLY_RIGHT) -----------------------------------------
+// What recon_task<TYPE, false, false, true, 0, 2, true, 1> does, cut in two at the point where the reference rows have been requested:
+// luma_back_fetch (the macroblock's flags and vectors from the chroma part's lanes, window geometry, the requests) and luma_back_rest
+// (row passes, prediction, stores, conversion).  Between a wave's request for reference rows and its first use of them lay one row
+// pass (~170 vector instructions); with the cut, the RIGHT part's rows are requested while the left part still has its last half to
+// convert and store (`hook`, called when the left part's own reference rows are dead: the registers are free), so they fly behind
+// ~310 instructions and two store instructions more.
+#ifndef LEON_EARLY_RIGHT
+#define LEON_EARLY_RIGHT 0
+#endif
+struct NoHook { __device__ __forceinline__ void operator()() const {} };
+struct LumaBack {
+    uint32_t out_voff;
+    int ovA, ovB;
+    bool nopred, usef, useb, any_f, any_b;
+    RefRows rfh[2], rbh[2];
+};
+
+template <int TYPE>
+__device__ __forceinline__ void luma_back_fetch(LumaBack& S, const PicDesc& pd, const Geom& G, int Rt, int g, const char* lds, int lane, int side,
+                                                const MbCarry& carry)
+{
+    const int W = G.cw, H = G.ch, bw = W >> 3;
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const int Qb = g * 8 + lo3;
+    const bool valid = Qb < bw;
+    const int Qs = valid ? Qb : bw - 1;
+    // this lane's macroblock is number 4 * side + (block >> 1) of the task: its chroma-part lane holds it
+    const int src = (4 * side + (lo3 >> 1)) << 2;
+    const uint32_t flags = (uint32_t)__builtin_amdgcn_ds_bpermute(src, (int)carry.flags);
+    uint32_t mf = *reinterpret_cast<const uint32_t*>(lds + Lay<1>::carry + src), mk = 0;
+    if (TYPE == 3) mk = *reinterpret_cast<const uint32_t*>(lds + Lay<1>::carry + 32 + src);
+    const int x0 = 8 * Qs;
+    bool nopred = (flags & 512u) != 0u, usef = true, useb = true;
+    if (TYPE == 3) {
+        const int dir = (int)(flags >> 10) & 3;
+        usef = (dir & 1) != 0;
+        useb = (dir & 2) != 0;
+        nopred = nopred || dir == 0;
+        if (!usef) mf = 0;
+        if (!useb) mk = 0;
+    }
+    const int fh = (int)(short)(mf & 0xffff), fv = (int)mf >> 16;
+    const int bh = (int)(short)(mk & 0xffff), bv = (int)mk >> 16;
+    const int pxA = x0 + (fh >> 1), ohA = fh & 1, ayA = fv >> 1, ovA = fv & 1;
+    bool inA = (uint32_t)pxA < (uint32_t)(W - 7 - ohA), inB = true;
+    int pxB = 0, ohB = 0, ayB = 0, ovB = 0;
+    if (TYPE == 3) {
+        pxB = x0 + (bh >> 1); ohB = bh & 1; ayB = bv >> 1; ovB = bv & 1;
+        inB = (uint32_t)pxB < (uint32_t)(W - 7 - ohB);
+    }
+    const bool useA = usef && !nopred, useB = useb && !nopred;
+    inA = inA || !useA;
+    inB = inB || !useB;
+    S.out_voff = ((uint32_t)__mul24(16 * Rt + hi3, W) + (uint32_t)x0) | (valid ? 0u : kOobBit);
+    S.ovA = ovA; S.ovB = ovB; S.nopred = nopred; S.usef = usef; S.useb = useb;
+    S.any_f = TYPE != 3 || __builtin_amdgcn_ballot_w64(useA) != 0;
+    S.any_b = TYPE == 3 && __builtin_amdgcn_ballot_w64(useB) != 0;
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        const bool ninth = hi3 == 7 && (h == 1 || !LEON_NINTH_FROM_BELOW);
+        if (S.any_f) S.rfh[h] = fetch_rows(gptr(pd.ref_fwd), W, H, 8 * (2 * Rt + h) + hi3, pxA, ayA, ohA, ovA, inA, ninth, useA);
+        if (TYPE == 3 && S.any_b) S.rbh[h] = fetch_rows(gptr(pd.ref_bwd), W, H, 8 * (2 * Rt + h) + hi3, pxB, ayB, ohB, ovB, inB, ninth, useB);
+    }
+}
+
+template <int TYPE, typename HOOK>
+__device__ __forceinline__ void luma_back_rest(LumaBack& S, const PicDesc& pd, const Geom& G, int Rt, int g, int lane, const Display& dsp, char* tile,
+                                               uint64_t live0, uint64_t live1, HOOK hook)
+{
+    const int hi3 = lane >> 3, lo3 = lane & 7;
+    const uint32_t half_step = 8u * (uint32_t)G.cw;
+    const uint64_t live[2] = {live0, live1};
+#pragma unroll
+    for (int half = 0; half < 2; half++) {
+        int t[8];
+        const uint64_t colbits = live[half];
+        if (colbits == 0) {
+#pragma unroll
+            for (int m = 0; m < 8; m++) t[m] = 128;
+        } else {
+            // stage 3, the row pass (recon_task)
+            const int cols_live = 8 - (__builtin_clzll(colbits | 1ull) >> 3);
+            const v4u wv = *reinterpret_cast<const v4u*>(tile + half * kLdsHalf + hi3 * 128 + lo3 * 16);
+            const v2f k25 = {2.5f, 2.5f};
+            const v2f a = v2f{(float)(short)(wv.x & 0xffffu), (float)((int)wv.x >> 16)} * k25;
+            const int Y0 = (int)a.x + 128, Y1 = (int)a.y;
+            if (cols_live <= 2) {
+                butterfly8_lo2(Y0, Y1, t);
+            } else {
+                const v2f bb = v2f{(float)(short)(wv.y & 0xffffu), (float)((int)wv.y >> 16)} * k25;
+                if (cols_live <= 4) {
+                    butterfly8_lo4(Y0, Y1, (int)bb.x, (int)bb.y, t);
+                } else {
+                    const v2f cc = v2f{(float)(short)(wv.z & 0xffffu), (float)((int)wv.z >> 16)} * k25;
+                    const v2f dd = v2f{(float)(short)(wv.w & 0xffffu), (float)((int)wv.w >> 16)} * k25;
+                    const int Y[8] = {Y0, Y1, (int)bb.x, (int)bb.y, (int)cc.x, (int)cc.y, (int)dd.x, (int)dd.y};
+                    butterfly8(Y, t);
+                }
+            }
+#pragma unroll
+            for (int m = 0; m < 8; m++) t[m] += (t[m] >> 31) & 255;
+        }
+        // stage 4: prediction, add, clamp, store
+        v2u pred = {0u, 0u};
+        if (S.any_f) {
+            finish_rows(S.rfh[half], S.ovA, hi3 == 7, lane, half == 0 && LEON_NINTH_FROM_BELOW ? &S.rfh[1] : nullptr);
+            pred = predict8(S.rfh[half]);
+        }
+        if (TYPE == 3) {
+            v2u pb = {0u, 0u};
+            if (S.any_b) {
+                finish_rows(S.rbh[half], S.ovB, hi3 == 7, lane, half == 0 && LEON_NINTH_FROM_BELOW ? &S.rbh[1] : nullptr);
+                pb = predict8(S.rbh[half]);
+            }
+            const v2u pf = S.usef ? pred : pb;
+            pb = S.useb ? pb : pred;
+            pred.x = __builtin_amdgcn_lerp(pf.x, pb.x, 0x01010101u);
+            pred.y = __builtin_amdgcn_lerp(pf.y, pb.y, 0x01010101u);
+        }
+        if (S.nopred) pred = v2u{0u, 0u};
+        t[0] += pred_x256<0>(pred.x);
+        t[1] += pred_x256<1>(pred.x);
+        t[2] += pred_x256<2>(pred.x);
+        t[3] += pred_x256<3>(pred.x);
+        t[4] += pred_x256<0>(pred.y);
+        t[5] += pred_x256<1>(pred.y);
+        t[6] += pred_x256<2>(pred.y);
+        t[7] += pred_x256<3>(pred.y);
+        v2u o;
+        o.x = sat_pk4<8>(t[0], t[1], t[2], t[3]);
+        o.y = sat_pk4<8>(t[4], t[5], t[6], t[7]);
+        // the part's own reference rows are dead: the next part's may be requested
+        if (half == 1) hook();
+        if (!pd.no_planes) __builtin_amdgcn_raw_buffer_store_b64(o, buf_rsrc(pd.out), (int)S.out_voff, (int)(half ? half_step : 0u), 0);
+        // the tile half is read out (stage 3): every lane's read has completed; the rows change lanes through it
+        wait_lds_all();
+        __builtin_amdgcn_wave_barrier();
+        *reinterpret_cast<v2u*>(tile + half * kLdsHalf + hi3 * 64 + lo3 * 8) = o;
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (!(LEON_ABL & 4)) display_half<0>(pd, G, dsp, tile + half * kLdsHalf, half, Rt, g, hi3, lo3);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+    }
+}
+
 // The two luma parts of a dense display task (P and B pictures) with ONE front: the coefficient rows of both parts are requested
 // together (two tiles), one liveness scan lists the live columns of all four halves, ONE column pass takes them -- a P or B part
 // has about a dozen live columns of 128, and a pass costs ~140 instructions however few of its 64 lanes have a column -- and then each
@@ -1166,6 +1315,15 @@ __device__ __forceinline__ void recon_luma_pair(const PicDesc& pd, const Geom& G
         coef_rows_to_lds(pd.coef[0], tileR, voff, 0u);
         coef_rows_to_lds(pd.coef[0], tileR + kLdsHalf, voff, 16u * (uint32_t)W);
     }
+#if LEON_EARLY_RIGHT
+    // P pictures (52 registers, five waves per SIMD by LDS: room for 96): the reference rows of BOTH parts are requested right behind
+    // the coefficient rows -- one trip to memory for everything the luma parts read
+    constexpr bool kRefsUpFront = LEON_EARLY_RIGHT >= 2 && TYPE == 2;
+    constexpr bool kLeftUpFront = kRefsUpFront || (LEON_EARLY_RIGHT == 4 && TYPE == 3);     // (B: the left part's only; 71 registers)
+    LumaBack backL, backR;
+    if (kLeftUpFront) luma_back_fetch<TYPE>(backL, pd, G, Rt, 2 * gc, lds, lane, 0, carry);
+    if (kRefsUpFront && has_right) luma_back_fetch<TYPE>(backR, pd, G, Rt, 2 * gc + 1, lds, lane, 1, carry);
+#endif
     if (LEON_PRIO_OF(TYPE) == 3) __builtin_amdgcn_s_setprio(0);
     // quantiser scale | intra << 8 of the macroblock of block b of either part, in lane b (the chroma part's lanes hold the task's
     // eight macroblocks: lane m, macroblock m)
@@ -1175,6 +1333,12 @@ __device__ __forceinline__ void recon_luma_pair(const PicDesc& pd, const Geom& G
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#if LEON_EARLY_RIGHT
+    // B pictures (70 registers of 72): the LEFT part's reference rows are requested as soon as the coefficient rows are in (a full
+    // wait in front of them would wait for these too) -- the scan and the column pass run while they fly
+    constexpr bool kLeftBeforeScan = LEON_EARLY_RIGHT == 3 && TYPE == 3;
+    if (kLeftBeforeScan) luma_back_fetch<TYPE>(backL, pd, G, Rt, 2 * gc, lds, lane, 0, carry);
+#endif
     uint64_t liveL[2], liveR[2] = {0, 0};
     uint32_t n_cols = scan_tile(lds, lds + Lay<1>::slots, lane, 0u, 0u, liveL);
     if (has_right) n_cols = scan_tile(tileR, lds + Lay<1>::slots, lane, 128u, n_cols, liveR);
@@ -1187,6 +1351,18 @@ __device__ __forceinline__ void recon_luma_pair(const PicDesc& pd, const Geom& G
     __builtin_amdgcn_wave_barrier();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     dsp.side = 0;
+#if LEON_EARLY_RIGHT
+    {
+        if (!kLeftUpFront && !kLeftBeforeScan) luma_back_fetch<TYPE>(backL, pd, G, Rt, 2 * gc, lds, lane, 0, carry);
+        luma_back_rest<TYPE>(backL, pd, G, Rt, 2 * gc, lane, dsp, lds, liveL[0], liveL[1],
+                             [&]() { if (!kRefsUpFront && has_right) luma_back_fetch<TYPE>(backR, pd, G, Rt, 2 * gc + 1, lds, lane, 1, carry); });
+        if (has_right) {
+            dsp.side = 1;
+            luma_back_rest<TYPE>(backR, pd, G, Rt, 2 * gc + 1, lane, dsp, tileR, liveR[0], liveR[1], NoHook{});
+        }
+        return;
+    }
+#endif
     recon_task<TYPE, false, false, true, 0, 2, true, 1>(pd, G, Rt, 2 * gc, lds, lane, dsp, carry, false, lds, liveL[0], liveL[1]);
     if (has_right) {
         if (LEON_PRIO_OF(TYPE) == 1) __builtin_amdgcn_s_setprio(3);
