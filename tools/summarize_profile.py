@@ -18,6 +18,10 @@ def main():
     ap.add_argument("--stats")
     ap.add_argument("--pmc", nargs="*", default=[])
     ap.add_argument("--note", default="")
+    ap.add_argument("--timed-launches", type=int, default=0,
+                    help="also write <tag>_kernel_stats_timed_region.csv: rocprofv3's stats columns over the LAST n reconstruction dispatches of the "
+                         "trace only (bench.py's timed steps x 8 launches, when nothing behind them launches k_recon*: --no-cpu-baseline "
+                         "--no-second-recipe --no-end-to-end) -- so that a run WITH the start-up placement step, whose draws launch the same kernels, can be traced")
     ap.add_argument("--out", default=os.path.join(ROOT, "profiles"), help="directory to write to (on the GPU box: somewhere under gpurun_out/)")
     a = ap.parse_args()
     out = a.out
@@ -33,6 +37,16 @@ def main():
                 for r in rows:
                     w.write('"%s",%s,%.3f\n' % (r["Kernel_Name"].split("(")[0], r["Grid_Size_X"],
                                               (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+            if a.timed_launches > 0:
+                rec = sorted((r for r in rows if "k_recon" in r["Kernel_Name"]), key=lambda r: int(r["Start_Timestamp"]))[-a.timed_launches:]
+                by = collections.OrderedDict()
+                for r in rec:
+                    by.setdefault(r["Kernel_Name"], []).append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+                tot = sum(sum(v) for v in by.values())
+                with open(os.path.join(out, a.tag + "_kernel_stats_timed_region.csv"), "w") as w:
+                    w.write('"Name","Calls","TotalDurationNs","AverageNs","Percentage","MinNs","MaxNs"\n')
+                    for k, v in sorted(by.items(), key=lambda kv: -sum(kv[1])):
+                        w.write('"%s",%d,%d,%.6f,%.2f,%d,%d\n' % (k, len(v), sum(v), sum(v) / len(v), 100.0 * sum(v) / tot, min(v), max(v)))
     pmc = collections.defaultdict(dict)
     for d in a.pmc:
         for f in glob.glob(os.path.join(d, "**", "*_counter_collection.csv"), recursive=True):
