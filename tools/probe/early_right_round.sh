@@ -4,7 +4,7 @@
 #   TAG=r04h bash tools/probe/early_right_round.sh
 tag=${TAG:-r04h}
 out=gpurun_out/r4/prof_$tag; mkdir -p $out/summary
-variants="tree er1 er2 er3 er4"
+variants=${VARIANTS:-"tree er1 er2 er3 er4"}     # VARIANTS="tree ilp memcl relax": builds with other scheduling strategies of the compiler
 timeout -k 10 600 python tools/ab_run.py $variants $variants -- --no-end-to-end --warmup 5 > $out/ab.log 2>&1 || { tail -5 $out/ab.log; exit 1; }
 cat $out/ab.log
 python - $out/ab.log > $out/choice.txt <<'EOF'
@@ -24,6 +24,7 @@ for name, v in ms.items():
 print(best)
 EOF
 choice=$(cat $out/choice.txt); echo "choice: $choice"
+if [ "$choice" = "tree" ] && [ -n "$STOP_IF_TREE" ]; then exit 0; fi
 if [ "$choice" != "tree" ]; then cp build/ab/$choice/libleon_hip.so mpeg1video-decoder-webgl_amd/lib/libleon_hip.so; fi
 timeout -k 10 600 python -m pytest tests -x -q -m gpu > $out/gpu_tests.log 2>&1 || { tail -30 $out/gpu_tests.log; exit 1; }
 tail -n 2 $out/gpu_tests.log
